@@ -1,0 +1,90 @@
+"""ctypes binding of ``csrc/liblssvr_hip.so`` (C ABI: ``include/lssvr_hip.h``).
+
+The library is the product; there is no CPU fallback.  Loading fails loudly when
+the shared object is missing, and every compute entry point needs device
+pointers on a visible MI355X.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "liblssvr_hip.so")
+
+ABI_VERSION = 1
+
+RHS_ARRAY = 0
+RHS_SIN = 1
+SOLVER_PRIMAL = 0
+SOLVER_DUAL = 1
+ST_OK = 0
+ST_FALLBACK = 1
+
+_c_dp = C.c_void_p      # device pointers travel as integers
+_c_i64 = C.c_int64
+_c_int = C.c_int
+_c_dbl = C.c_double
+
+# name -> (restype, argtypes); mirrors include/lssvr_hip.h declaration by declaration
+SIGNATURES = {
+    "lssvr_version": (_c_int, []),
+    "lssvr_last_error": (C.c_char_p, []),
+    "lssvr_enhance": (_c_int, [_c_dp, _c_dp, _c_i64, _c_i64, _c_i64,
+                               _c_dbl, _c_dbl, _c_dbl, _c_dbl,
+                               _c_int, _c_int, _c_dbl,
+                               _c_int, C.POINTER(_c_dbl), _c_dp, _c_int,
+                               _c_dp, _c_dp, _c_dp, _c_dp]),
+    "lssvr_enhance_varcoef": (_c_int, [_c_dp, _c_dp, _c_i64, _c_i64, _c_i64,
+                                       _c_dbl, _c_dbl, _c_dbl, _c_dbl,
+                                       _c_int, _c_int, _c_dbl,
+                                       _c_dp, _c_dp, _c_dp,
+                                       _c_dp, _c_dp, _c_dp, _c_dp]),
+    "lssvr_colloc_points": (_c_int, [_c_dp, _c_i64, _c_int, _c_dp, _c_dp]),
+    "lssvr_p1_assemble": (_c_int, [_c_dp, _c_i64, _c_int, _c_int, C.POINTER(_c_dbl), _c_dp, _c_dp,
+                                   _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp]),
+    "lssvr_quad_points": (_c_int, [_c_dp, _c_i64, _c_int, _c_dp, _c_dp]),
+    "lssvr_tridiag_work_bytes": (_c_i64, [_c_i64]),
+    "lssvr_tridiag_dirichlet_solve": (_c_int, [_c_dp, _c_dp, _c_dp, _c_i64, _c_dbl, _c_dbl,
+                                               _c_dp, _c_dp, _c_dp]),
+    "lssvr_eval": (_c_int, [_c_dp, _c_dp, _c_i64, _c_int, _c_dp, _c_i64, _c_dp, _c_dp, _c_dp]),
+    "lssvr_fp64_probe": (_c_int, [_c_dp, _c_int, _c_int, _c_int, _c_dp]),
+}
+
+_lib = None
+
+
+class LssvrHipError(RuntimeError):
+    """A C-ABI entry point returned a negative status."""
+
+
+def load():
+    """dlopen the HIP library once; raise if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` or `make -C hybrid_fem_lssvr_amd/csrc` (there is no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    ver = lib.lssvr_version()
+    if ver != ABI_VERSION:
+        raise ImportError(f"liblssvr_hip.so has ABI {ver}, binding expects {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc < 0:
+        msg = load().lssvr_last_error().decode("utf-8", "replace")
+        raise LssvrHipError(f"{what} failed ({rc}): {msg}")
+    return rc
+
+
+def rhs_params(amp, omega):
+    return (_c_dbl * 2)(float(amp), float(omega))

@@ -1,0 +1,200 @@
+// extern "C" layer: argument validation, error strings, dispatch.  No torch,
+// no Python types -- plain pointers and sizes (include/lssvr_hip.h).
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "lssvr_kernels.hpp"
+
+namespace {
+
+thread_local char g_err[256] = {0};
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int check_launch(hipError_t e, const char* what) {
+  if (e == hipSuccess) return LSSVR_OK;
+  return fail(LSSVR_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+}
+
+int fill_enhance_args(lssvr::EnhanceArgs& a, const double* x, const double* u, int64_t ne,
+                      int64_t elem_offset, int64_t ne_global, double gxmin, double gxmax,
+                      double bc_left, double bc_right, int M, int n_colloc, double gamma,
+                      double* W) {
+  if (ne < 0) return fail(LSSVR_ERR_SIZE, "ne = %lld < 0", (long long)ne);
+  if (ne > 0 && (!x || !u || !W)) return fail(LSSVR_ERR_NULL, "x, u and W must be non-NULL");
+  if (elem_offset < 0 || ne_global < elem_offset + ne)
+    return fail(LSSVR_ERR_SIZE, "shard [%lld, %lld) does not fit ne_global = %lld",
+                (long long)elem_offset, (long long)(elem_offset + ne), (long long)ne_global);
+  if (M < 2 || M > lssvr::kLargeMaxM)
+    return fail(LSSVR_ERR_DEGREE, "M = %d outside [2, %d]", M, lssvr::kLargeMaxM);
+  if (n_colloc < 2 || n_colloc > 4096)
+    return fail(LSSVR_ERR_SIZE, "n_colloc = %d outside [2, 4096]", n_colloc);
+  if (!(gamma > 0.0)) return fail(LSSVR_ERR_SIZE, "gamma must be > 0");
+  if (ne * (int64_t)M / M != ne) return fail(LSSVR_ERR_SIZE, "ne*M overflows");
+  a = lssvr::EnhanceArgs{};
+  a.x = x;
+  a.u = u;
+  a.ne = ne;
+  a.elem_offset = elem_offset;
+  a.ne_global = ne_global;
+  a.gxmin = gxmin;
+  a.gxmax = gxmax;
+  a.bc_left = bc_left;
+  a.bc_right = bc_right;
+  a.gamma = gamma;
+  a.M = M;
+  a.n = n_colloc;
+  a.W = W;
+  return LSSVR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lssvr_version(void) { return LSSVR_ABI_VERSION; }
+
+const char* lssvr_last_error(void) { return g_err; }
+
+int lssvr_enhance(const double* x, const double* u, int64_t ne, int64_t elem_offset,
+                  int64_t ne_global, double gxmin, double gxmax, double bc_left, double bc_right,
+                  int M, int n_colloc, double gamma, int rhs_id, const double* rhs_params_host,
+                  const double* rhs_values, int solver_id, double* W, int32_t* status,
+                  int32_t* fail_count, void* stream) {
+  lssvr::EnhanceArgs a;
+  int rc = fill_enhance_args(a, x, u, ne, elem_offset, ne_global, gxmin, gxmax, bc_left, bc_right,
+                             M, n_colloc, gamma, W);
+  if (rc != LSSVR_OK) return rc;
+  a.rhs_id = rhs_id;
+  if (rhs_id == LSSVR_RHS_SIN) {
+    if (!rhs_params_host) return fail(LSSVR_ERR_RHS, "LSSVR_RHS_SIN needs rhs_params = {amp, omega}");
+    a.rhs_amp = rhs_params_host[0];
+    a.rhs_omega = rhs_params_host[1];
+  } else if (rhs_id == LSSVR_RHS_ARRAY) {
+    if (ne > 0 && !rhs_values) return fail(LSSVR_ERR_RHS, "LSSVR_RHS_ARRAY needs rhs_values[ne*n_colloc]");
+    a.rhs_values = rhs_values;
+  } else {
+    return fail(LSSVR_ERR_RHS, "unknown rhs_id %d", rhs_id);
+  }
+  a.status = status;
+  a.fail_count = fail_count;
+  if (solver_id != LSSVR_SOLVER_PRIMAL && solver_id != LSSVR_SOLVER_DUAL)
+    return fail(LSSVR_ERR_SOLVER, "unknown solver_id %d", solver_id);
+  if (ne == 0) return LSSVR_OK;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (solver_id == LSSVR_SOLVER_DUAL) return check_launch(lssvr::enhance_dual(a, s), "enhance_dual");
+  if (M <= lssvr::kSmallMaxM) return check_launch(lssvr::enhance_small(a, s), "enhance_small");
+  return check_launch(lssvr::enhance_large(a, s), "enhance_large");
+}
+
+int lssvr_enhance_varcoef(const double* x, const double* u, int64_t ne, int64_t elem_offset,
+                          int64_t ne_global, double gxmin, double gxmax, double bc_left,
+                          double bc_right, int M, int n_colloc, double gamma,
+                          const double* a_values, const double* da_values,
+                          const double* rhs_values, double* W, int32_t* status,
+                          int32_t* fail_count, void* stream) {
+  lssvr::EnhanceArgs a;
+  int rc = fill_enhance_args(a, x, u, ne, elem_offset, ne_global, gxmin, gxmax, bc_left, bc_right,
+                             M, n_colloc, gamma, W);
+  if (rc != LSSVR_OK) return rc;
+  if (ne > 0 && (!a_values || !da_values || !rhs_values))
+    return fail(LSSVR_ERR_NULL, "a_values, da_values and rhs_values must be non-NULL");
+  a.rhs_id = LSSVR_RHS_ARRAY;
+  a.rhs_values = rhs_values;
+  a.a_values = a_values;
+  a.da_values = da_values;
+  a.status = status;
+  a.fail_count = fail_count;
+  if (ne == 0) return LSSVR_OK;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (M <= lssvr::kSmallMaxM) return check_launch(lssvr::enhance_small(a, s), "enhance_small(varcoef)");
+  return check_launch(lssvr::enhance_large(a, s), "enhance_large(varcoef)");
+}
+
+int lssvr_colloc_points(const double* x, int64_t ne, int n_colloc, double* xc, void* stream) {
+  if (ne < 0) return fail(LSSVR_ERR_SIZE, "ne < 0");
+  if (n_colloc < 2) return fail(LSSVR_ERR_SIZE, "n_colloc < 2");
+  if (ne > 0 && (!x || !xc)) return fail(LSSVR_ERR_NULL, "x and xc must be non-NULL");
+  return check_launch(lssvr::colloc_points(x, ne, n_colloc, xc, reinterpret_cast<hipStream_t>(stream)),
+                      "colloc_points");
+}
+
+int lssvr_p1_assemble(const double* x, int64_t ne, int nquad, int rhs_id,
+                      const double* rhs_params_host, const double* rhs_quad, const double* a_quad,
+                      double* diag, double* off, double* load, double* kloc, double* floc,
+                      void* stream) {
+  if (ne < 1) return fail(LSSVR_ERR_SIZE, "ne = %lld < 1", (long long)ne);
+  if (!x || !diag || !off || !load) return fail(LSSVR_ERR_NULL, "x, diag, off, load must be non-NULL");
+  if (nquad < 1 || nquad > 5) return fail(LSSVR_ERR_QUAD, "nquad = %d outside [1,5]", nquad);
+  lssvr::P1Args a{};
+  a.x = x;
+  a.ne = ne;
+  a.nquad = nquad;
+  a.rhs_id = rhs_id;
+  if (rhs_id == LSSVR_RHS_SIN) {
+    if (!rhs_params_host) return fail(LSSVR_ERR_RHS, "LSSVR_RHS_SIN needs rhs_params = {amp, omega}");
+    a.rhs_amp = rhs_params_host[0];
+    a.rhs_omega = rhs_params_host[1];
+  } else if (rhs_id == LSSVR_RHS_ARRAY) {
+    if (!rhs_quad) return fail(LSSVR_ERR_RHS, "LSSVR_RHS_ARRAY needs rhs_quad[ne*nquad]");
+    a.rhs_quad = rhs_quad;
+  } else {
+    return fail(LSSVR_ERR_RHS, "unknown rhs_id %d", rhs_id);
+  }
+  a.a_quad = a_quad;
+  a.diag = diag;
+  a.off = off;
+  a.load = load;
+  a.kloc = kloc;
+  a.floc = floc;
+  return check_launch(lssvr::p1_assemble(a, reinterpret_cast<hipStream_t>(stream)), "p1_assemble");
+}
+
+int lssvr_quad_points(const double* x, int64_t ne, int nquad, double* xq, void* stream) {
+  if (ne < 0) return fail(LSSVR_ERR_SIZE, "ne < 0");
+  if (nquad < 1 || nquad > 5) return fail(LSSVR_ERR_QUAD, "nquad = %d outside [1,5]", nquad);
+  if (ne > 0 && (!x || !xq)) return fail(LSSVR_ERR_NULL, "x and xq must be non-NULL");
+  return check_launch(lssvr::quad_points(x, ne, nquad, xq, reinterpret_cast<hipStream_t>(stream)),
+                      "quad_points");
+}
+
+int64_t lssvr_tridiag_work_bytes(int64_t ne) { return lssvr::tridiag_work_bytes(ne); }
+
+int lssvr_tridiag_dirichlet_solve(const double* diag, const double* off, const double* load,
+                                  int64_t ne, double u0, double u1, double* u, void* work,
+                                  void* stream) {
+  if (ne < 1) return fail(LSSVR_ERR_SIZE, "ne = %lld < 1", (long long)ne);
+  if (!diag || !off || !load || !u || !work)
+    return fail(LSSVR_ERR_NULL, "diag, off, load, u, work must be non-NULL");
+  return check_launch(lssvr::tridiag_dirichlet_solve(diag, off, load, ne, u0, u1, u, work,
+                                                     reinterpret_cast<hipStream_t>(stream)),
+                      "tridiag_dirichlet_solve");
+}
+
+int lssvr_eval(const double* x, const double* W, int64_t ne, int M, const double* xq, int64_t P,
+               double* uq, int64_t* elem, void* stream) {
+  if (ne < 1) return fail(LSSVR_ERR_SIZE, "ne = %lld < 1", (long long)ne);
+  if (P < 0) return fail(LSSVR_ERR_SIZE, "P < 0");
+  if (M < 1) return fail(LSSVR_ERR_DEGREE, "M = %d < 1", M);
+  if (!x || !W || (P > 0 && (!xq || !uq))) return fail(LSSVR_ERR_NULL, "x, W, xq, uq must be non-NULL");
+  return check_launch(lssvr::eval_points(x, W, ne, M, xq, P, uq, elem,
+                                         reinterpret_cast<hipStream_t>(stream)),
+                      "eval_points");
+}
+
+int lssvr_fp64_probe(double* out, int blocks, int iters, int use_mfma, void* stream) {
+  if (!out) return fail(LSSVR_ERR_NULL, "out must be non-NULL");
+  if (blocks < 1 || iters < 1) return fail(LSSVR_ERR_SIZE, "blocks and iters must be >= 1");
+  return check_launch(lssvr::fp64_probe(out, blocks, iters, use_mfma,
+                                        reinterpret_cast<hipStream_t>(stream)),
+                      "fp64_probe");
+}
+
+}  // extern "C"

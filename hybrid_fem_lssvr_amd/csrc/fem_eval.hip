@@ -1,0 +1,284 @@
+// Kernels either side of the enhancement: collocation / quadrature abscissae,
+// element-local P1 assembly (Dual.py:117-128), evaluate_solution (Dual.py:176-203)
+// and the FP64 peak probe used for the roofline.
+#include "lssvr_device.hpp"
+#include "lssvr_kernels.hpp"
+
+namespace lssvr {
+
+// ---------------------------------------------------------------------------
+// np.linspace(x[e], x[e+1], n) for every element  (Dual.py:40)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void colloc_points_kernel(const double* __restrict__ x,
+                                                                int64_t ne, int n,
+                                                                double* __restrict__ xc) {
+  const int64_t total = ne * n;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * kBlock) {
+    const int64_t e = i / n;
+    const int k = (int)(i - e * n);
+    const double a = x[e], b = x[e + 1];
+    const double delta = b - a;
+    const double step = delta / (double)(n - 1);
+    xc[i] = linspace_at(a, b, delta, step, k, n);
+  }
+}
+
+hipError_t colloc_points(const double* x, int64_t ne, int n, double* xc, hipStream_t s) {
+  if (ne == 0) return hipSuccess;
+  const int64_t total = ne * n;
+  const unsigned blocks = (unsigned)((total + kBlock - 1) / kBlock < 8192 ? (total + kBlock - 1) / kBlock : 8192);
+  hipLaunchKernelGGL(colloc_points_kernel, dim3(blocks), dim3(kBlock), 0, s, x, ne, n, xc);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Gauss-Legendre rules on [0,1] (abscissa xi, weight w; weights sum to 1)
+// ---------------------------------------------------------------------------
+struct QuadRule {
+  double xi[5];
+  double wt[5];
+};
+
+static bool quad_rule(int nq, QuadRule& q) {
+  static const double X1[] = {0.5};
+  static const double W1[] = {1.0};
+  static const double X2[] = {0.21132486540518711775, 0.78867513459481288225};
+  static const double W2[] = {0.5, 0.5};
+  static const double X3[] = {0.11270166537925831148, 0.5, 0.88729833462074168852};
+  static const double W3[] = {0.27777777777777777778, 0.44444444444444444444,
+                              0.27777777777777777778};
+  static const double X4[] = {0.069431844202973712388, 0.33000947820757186760,
+                              0.66999052179242813240, 0.93056815579702628761};
+  static const double W4[] = {0.17392742256872692869, 0.32607257743127307131,
+                              0.32607257743127307131, 0.17392742256872692869};
+  static const double X5[] = {0.046910077030668003601, 0.23076534494715845448, 0.5,
+                              0.76923465505284154552, 0.95308992296933199640};
+  static const double W5[] = {0.11846344252809454376, 0.23931433524968323402,
+                              0.28444444444444444444, 0.23931433524968323402,
+                              0.11846344252809454376};
+  const double* X[] = {X1, X2, X3, X4, X5};
+  const double* W[] = {W1, W2, W3, W4, W5};
+  if (nq < 1 || nq > 5) return false;
+  for (int i = 0; i < 5; ++i) {
+    q.xi[i] = i < nq ? X[nq - 1][i] : 0.0;
+    q.wt[i] = i < nq ? W[nq - 1][i] : 0.0;
+  }
+  return true;
+}
+
+__global__ __launch_bounds__(kBlock) void quad_points_kernel(const double* __restrict__ x,
+                                                              int64_t ne, int nq, QuadRule q,
+                                                              double* __restrict__ xq) {
+  const int64_t total = ne * nq;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * kBlock) {
+    const int64_t e = i / nq;
+    const int k = (int)(i - e * nq);
+    const double a = x[e];
+    const double h = x[e + 1] - a;
+    xq[i] = a + h * q.xi[k];
+  }
+}
+
+hipError_t quad_points(const double* x, int64_t ne, int nquad, double* xq, hipStream_t s) {
+  QuadRule q;
+  if (!quad_rule(nquad, q)) return hipErrorInvalidValue;
+  if (ne == 0) return hipSuccess;
+  const int64_t total = ne * nquad;
+  const unsigned blocks = (unsigned)((total + kBlock - 1) / kBlock < 8192 ? (total + kBlock - 1) / kBlock : 8192);
+  hipLaunchKernelGGL(quad_points_kernel, dim3(blocks), dim3(kBlock), 0, s, x, ne, nquad, q, xq);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// element-local P1 stiffness / load + gather-assembly of the tridiagonal bands
+// ---------------------------------------------------------------------------
+// One thread per NODE i: it evaluates the element to its right (i) and the
+// element to its left (i-1) and sums their contributions, so the scatter of
+// Dual.py:127-128 becomes a race-free gather (no atomics, bitwise reproducible).
+struct ElemLocal {
+  double k, fl, fr;
+};
+
+template <bool SIN>
+__device__ __forceinline__ ElemLocal p1_element(const P1Args& p, const QuadRule& q, int64_t e) {
+  const double a = p.x[e];
+  const double h = p.x[e + 1] - a;
+  double sl = 0.0, sr = 0.0, am = 0.0;
+  for (int k = 0; k < p.nquad; ++k) {
+    const double xi = q.xi[k];
+    double f;
+    if constexpr (SIN) {
+      const double xq = a + h * xi;
+      f = p.rhs_amp * sin_reduced(p.rhs_omega * xq);
+    } else {
+      f = p.rhs_quad[e * p.nquad + k];
+    }
+    sl += (q.wt[k] * (1.0 - xi)) * f;
+    sr += (q.wt[k] * xi) * f;
+    if (p.a_quad) am += q.wt[k] * p.a_quad[e * p.nquad + k];
+  }
+  ElemLocal r;
+  r.k = (p.a_quad ? am : 1.0) / h;
+  r.fl = h * sl;
+  r.fr = h * sr;
+  return r;
+}
+
+template <bool SIN>
+__global__ __launch_bounds__(kBlock) void p1_assemble_kernel(P1Args p, QuadRule q) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i <= p.ne;
+       i += (int64_t)gridDim.x * kBlock) {
+    double d = 0.0, l = 0.0;
+    if (i < p.ne) {
+      const ElemLocal r = p1_element<SIN>(p, q, i);
+      d += r.k;
+      l += r.fl;
+      p.off[i] = -r.k;
+      if (p.kloc) p.kloc[i] = r.k;
+      if (p.floc) {
+        p.floc[2 * i] = r.fl;
+        p.floc[2 * i + 1] = r.fr;
+      }
+    }
+    if (i > 0) {
+      const ElemLocal r = p1_element<SIN>(p, q, i - 1);
+      d += r.k;
+      l += r.fr;
+    }
+    p.diag[i] = d;
+    p.load[i] = l;
+  }
+}
+
+hipError_t p1_assemble(const P1Args& a, hipStream_t s) {
+  QuadRule q;
+  if (!quad_rule(a.nquad, q)) return hipErrorInvalidValue;
+  const int64_t nn = a.ne + 1;
+  const unsigned blocks = (unsigned)((nn + kBlock - 1) / kBlock < 16384 ? (nn + kBlock - 1) / kBlock : 16384);
+  if (a.rhs_id == LSSVR_RHS_SIN)
+    hipLaunchKernelGGL(p1_assemble_kernel<true>, dim3(blocks), dim3(kBlock), 0, s, a, q);
+  else
+    hipLaunchKernelGGL(p1_assemble_kernel<false>, dim3(blocks), dim3(kBlock), 0, s, a, q);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// evaluate_solution (Dual.py:176-203)
+// ---------------------------------------------------------------------------
+// Element of a query point: the first j with x[j] <= xq <= x[j+1]
+//   == clamp(#{nodes < xq} - 1, 0, ne-1)      (a point on an interior node takes
+// the left element; outside the mesh the first / last element extrapolates).
+__device__ __forceinline__ int64_t locate(const double* __restrict__ x, int64_t ne, double xq,
+                                          double x0, double inv_h) {
+  // uniform-mesh guess, verified against the actual nodes
+  double g = (xq - x0) * inv_h;
+  int64_t j = g > 0.0 ? (g < (double)(ne - 1) ? (int64_t)g : ne - 1) : 0;
+#pragma unroll 1
+  for (int it = 0; it < 3; ++it) {
+    const bool lo_ok = (j == 0) || (x[j] < xq);
+    const bool hi_ok = (j == ne - 1) || (xq <= x[j + 1]);
+    if (lo_ok && hi_ok) return j;
+    j += lo_ok ? 1 : -1;
+  }
+  // general mesh: lower_bound over the ne+1 nodes
+  int64_t lo = 0, hi = ne + 1;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (x[mid] < xq) lo = mid + 1; else hi = mid;
+  }
+  j = lo - 1;
+  return j < 0 ? 0 : (j > ne - 1 ? ne - 1 : j);
+}
+
+__global__ __launch_bounds__(kBlock) void eval_kernel(const double* __restrict__ x,
+                                                       const double* __restrict__ W, int64_t ne,
+                                                       int M, const double* __restrict__ xq,
+                                                       int64_t P, double* __restrict__ uq,
+                                                       int64_t* __restrict__ elem) {
+  const double x0 = x[0];
+  const double inv_h = (double)ne / (x[ne] - x0);
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < P;
+       i += (int64_t)gridDim.x * kBlock) {
+    const double xi = xq[i];
+    if (xi != xi) {  // NaN: no branch of Dual.py:182-201 fires, the zero stays
+      uq[i] = 0.0;
+      if (elem) elem[i] = -1;
+      continue;
+    }
+    const int64_t j = locate(x, ne, xi, x0, inv_h);
+    const DomainMap dm = map_params(x[j], x[j + 1]);
+    const double t = dm.off + dm.scl * xi;      // mapdomain, two roundings
+    const double* c = W + j * M;
+    double c0, c1;
+    if (M == 1) {
+      c0 = c[0];
+      c1 = 0.0;
+    } else if (M == 2) {
+      c0 = c[0];
+      c1 = c[1];
+    } else {
+      // numpy legval: c0 = c[-i] - (c1*(nd-1))/nd ; c1 = tmp + (c1*x*(2*nd-1))/nd
+      int nd = M;
+      c0 = c[M - 2];
+      c1 = c[M - 1];
+      for (int k = 3; k <= M; ++k) {
+        const double tmp = c0;
+        nd = nd - 1;
+        c0 = c[M - k] - (c1 * (double)(nd - 1)) / (double)nd;
+        c1 = tmp + ((c1 * t) * (double)(2 * nd - 1)) / (double)nd;
+      }
+    }
+    uq[i] = c0 + c1 * t;
+    if (elem) elem[i] = j;
+  }
+}
+
+hipError_t eval_points(const double* x, const double* W, int64_t ne, int M, const double* xq,
+                       int64_t P, double* uq, int64_t* elem, hipStream_t s) {
+  if (P == 0) return hipSuccess;
+  const unsigned blocks = (unsigned)((P + kBlock - 1) / kBlock < 16384 ? (P + kBlock - 1) / kBlock : 16384);
+  hipLaunchKernelGGL(eval_kernel, dim3(blocks), dim3(kBlock), 0, s, x, W, ne, M, xq, P, uq, elem);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// FP64 peak probe
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void fp64_fma_probe_kernel(double* out, int iters) {
+  const int tid = blockIdx.x * kBlock + threadIdx.x;
+  double a0 = 1.0 + tid * 1e-9, a1 = a0 + 0.1, a2 = a0 + 0.2, a3 = a0 + 0.3;
+  double a4 = a0 + 0.4, a5 = a0 + 0.5, a6 = a0 + 0.6, a7 = a0 + 0.7;
+  const double m = 0.999999, c = 1e-7;
+  for (int i = 0; i < iters; ++i) {
+    a0 = fma(a0, m, c); a1 = fma(a1, m, c); a2 = fma(a2, m, c); a3 = fma(a3, m, c);
+    a4 = fma(a4, m, c); a5 = fma(a5, m, c); a6 = fma(a6, m, c); a7 = fma(a7, m, c);
+  }
+  out[tid] = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+}
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(kBlock) void fp64_mfma_probe_kernel(double* out, int iters) {
+  const int tid = blockIdx.x * kBlock + threadIdx.x;
+  double4_t c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+  const double a = 1.0 + (tid & 63) * 1e-3, b = 1.0 - (tid & 63) * 1e-3;
+  for (int i = 0; i < iters; ++i) {
+    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c2, 0, 0, 0);
+    c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c3, 0, 0, 0);
+  }
+  out[tid] = (c0[0] + c1[1]) + (c2[2] + c3[3]);
+}
+
+hipError_t fp64_probe(double* out, int blocks, int iters, int use_mfma, hipStream_t s) {
+  if (use_mfma)
+    hipLaunchKernelGGL(fp64_mfma_probe_kernel, dim3(blocks), dim3(kBlock), 0, s, out, iters);
+  else
+    hipLaunchKernelGGL(fp64_fma_probe_kernel, dim3(blocks), dim3(kBlock), 0, s, out, iters);
+  return hipGetLastError();
+}
+
+}  // namespace lssvr

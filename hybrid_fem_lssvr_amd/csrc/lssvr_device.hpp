@@ -1,0 +1,135 @@
+// Device-side building blocks shared by the gfx950 kernels.
+//
+// Everything here is FP64.  The translation units are compiled with
+// -ffp-contract=off: the places that mirror numpy's two-rounding arithmetic
+// (linspace, mapdomain, legval) rely on it, and every fused multiply-add that
+// is wanted is written as an explicit fma().
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lssvr {
+
+constexpr int kBlock = 256;  // 4 waves of 64: one wave per SIMD per workgroup
+
+// ---------------------------------------------------------------------------
+// numpy arithmetic mirrored on the device
+// ---------------------------------------------------------------------------
+
+// polyutils.mapparms(old=[a,b], new=[-1,1]): off = (b*(-1) - a*1)/oldlen, scl = 2/oldlen
+struct DomainMap {
+  double off, scl, oldlen;
+};
+__device__ __forceinline__ DomainMap map_params(double a, double b) {
+  DomainMap m;
+  m.oldlen = b - a;
+  m.off = (-b - a) / m.oldlen;
+  m.scl = 2.0 / m.oldlen;
+  return m;
+}
+
+// np.linspace(a, b, n)[k]: fl(fl(k*step) + a), last sample forced to b
+// (numpy/_core/function_base.py:140-175; step == 0 -> fl(fl(k/div)*delta) + a).
+__device__ __forceinline__ double linspace_at(double a, double b, double delta, double step, int k,
+                                              int n) {
+  if (k == n - 1) return b;
+  double y = (step == 0.0) ? ((double)k / (double)(n - 1)) * delta : (double)k * step;
+  return y + a;
+}
+
+// ---------------------------------------------------------------------------
+// sin for the in-kernel right-hand side
+// ---------------------------------------------------------------------------
+// sin(arg) for |arg| < 2^30*pi: arg = j*pi + r, |r| <= pi/2, two-term FMA
+// reduction, then the odd Taylor polynomial through r^21 (truncation
+// (pi/2)^23/23! = 1.3e-18).  Larger arguments go to the ocml routine.
+__device__ __forceinline__ double sin_reduced(double arg) {
+  constexpr double kInvPi = 0.31830988618379067154;
+  constexpr double kPiHi = 3.14159265358979311600e+00;
+  constexpr double kPiLo = 1.22464679914735317723e-16;
+  if (!(fabs(arg) < 3.0e9)) return sin(arg);
+  const double j = rint(arg * kInvPi);
+  double r = fma(-j, kPiHi, arg);
+  r = fma(-j, kPiLo, r);
+  const double z = r * r;
+  double p = -1.0 / 51090942171709440000.0;             // -1/21!
+  p = fma(p, z, 1.0 / 121645100408832000.0);            //  1/19!
+  p = fma(p, z, -1.0 / 355687428096000.0);              // -1/17!
+  p = fma(p, z, 1.0 / 1307674368000.0);                 //  1/15!
+  p = fma(p, z, -1.0 / 6227020800.0);                   // -1/13!
+  p = fma(p, z, 1.0 / 39916800.0);                      //  1/11!
+  p = fma(p, z, -1.0 / 362880.0);                       // -1/9!
+  p = fma(p, z, 1.0 / 5040.0);                          //  1/7!
+  p = fma(p, z, -1.0 / 120.0);                          // -1/5!
+  p = fma(p, z, 1.0 / 6.0);                             //  1/3!  (sign folded below)
+  // sin r = r - r^3/6 + ... = r - r*z*(1/6 - z/120 + ...)
+  const double s = fma(-(r * z), p, r);
+  const long long ji = (long long)j;
+  return (ji & 1) ? -s : s;
+}
+
+// 1/sqrt(x) to ~1 ulp: hardware seed (v_rsq_f64, ~2^-26 rel.) + two Newton steps.
+__device__ __forceinline__ double rsqrt_newton(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  double h = 0.5 * x;
+  y = y * fma(-h * y, y, 1.5);
+  y = y * fma(-h * y, y, 1.5);
+  return y;
+}
+
+// 1/x to ~1 ulp: v_rcp_f64 seed + two Newton steps.
+__device__ __forceinline__ double rcp_newton(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = y * fma(-x, y, 2.0);
+  y = y * fma(-x, y, 2.0);
+  return y;
+}
+
+// ---------------------------------------------------------------------------
+// Legendre families by three-term recurrences (compile-time coefficients)
+// ---------------------------------------------------------------------------
+// q[m] = L''_{m+2}(t) = 3 C^{(5/2)}_m(t):  q0 = 3, q1 = 15 t,
+//   m q_m = (2m+3) t q_{m-1} - (m+3) q_{m-2}
+template <int MR>
+__device__ __forceinline__ void legendre_d2(double t, double (&q)[MR]) {
+  if constexpr (MR > 0) q[0] = 3.0;
+  if constexpr (MR > 1) q[1] = 15.0 * t;
+#pragma unroll
+  for (int m = 2; m < MR; ++m) {
+    const double al = (double)(2 * m + 3) / (double)m;
+    const double be = (double)(m + 3) / (double)m;
+    q[m] = fma(al * t, q[m - 1], -(be * q[m - 2]));
+  }
+}
+
+// r[m] = L'_{m+1}(t) = C^{(3/2)}_m(t):  r0 = 1, r1 = 3 t,
+//   m r_m = (2m+1) t r_{m-1} - (m+1) r_{m-2}
+template <int MD>
+__device__ __forceinline__ void legendre_d1(double t, double (&r)[MD]) {
+  if constexpr (MD > 0) r[0] = 1.0;
+  if constexpr (MD > 1) r[1] = 3.0 * t;
+#pragma unroll
+  for (int m = 2; m < MD; ++m) {
+    const double al = (double)(2 * m + 1) / (double)m;
+    const double be = (double)(m + 1) / (double)m;
+    r[m] = fma(al * t, r[m - 1], -(be * r[m - 2]));
+  }
+}
+
+// L_p(t), p < M:  (p+1) L_{p+1} = (2p+1) t L_p - p L_{p-1}
+template <int M>
+__device__ __forceinline__ void legendre_p(double t, double (&L)[M]) {
+  L[0] = 1.0;
+  if constexpr (M > 1) L[1] = t;
+#pragma unroll
+  for (int p = 1; p < M - 1; ++p) {
+    const double al = (double)(2 * p + 1) / (double)(p + 1);
+    const double be = (double)p / (double)(p + 1);
+    L[p + 1] = fma(al * t, L[p], -(be * L[p - 1]));
+  }
+}
+
+// packed lower-triangular index, j <= i
+__host__ __device__ constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }
+
+}  // namespace lssvr

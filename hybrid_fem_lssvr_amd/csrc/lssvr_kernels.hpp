@@ -1,0 +1,61 @@
+// Internal launch interface between the C-ABI layer (capi.hip) and the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/lssvr_hip.h"
+
+namespace lssvr {
+
+constexpr int kSmallMaxM = 14;   // lane-per-element path: M-2 <= 12 register-resident
+constexpr int kLargeMaxM = 34;   // half-wave-per-element path: M-2 <= 32
+
+struct EnhanceArgs {
+  const double* x;
+  const double* u;
+  int64_t ne, elem_offset, ne_global;
+  double gxmin, gxmax, bc_left, bc_right, gamma;
+  int M, n;
+  int rhs_id;
+  double rhs_amp, rhs_omega;
+  const double* rhs_values;
+  const double* a_values;   // non-null => variable-coefficient rows
+  const double* da_values;
+  double* W;
+  int32_t* status;
+  int32_t* fail_count;
+};
+
+hipError_t enhance_small(const EnhanceArgs& a, hipStream_t s);
+hipError_t enhance_large(const EnhanceArgs& a, hipStream_t s);
+hipError_t enhance_dual(const EnhanceArgs& a, hipStream_t s);
+
+hipError_t colloc_points(const double* x, int64_t ne, int n, double* xc, hipStream_t s);
+
+struct P1Args {
+  const double* x;
+  int64_t ne;
+  int nquad;
+  int rhs_id;
+  double rhs_amp, rhs_omega;
+  const double* rhs_quad;
+  const double* a_quad;
+  double* diag;
+  double* off;
+  double* load;
+  double* kloc;
+  double* floc;
+};
+hipError_t p1_assemble(const P1Args& a, hipStream_t s);
+hipError_t quad_points(const double* x, int64_t ne, int nquad, double* xq, hipStream_t s);
+
+int64_t tridiag_work_bytes(int64_t ne);
+hipError_t tridiag_dirichlet_solve(const double* diag, const double* off, const double* load,
+                                   int64_t ne, double u0, double u1, double* u, void* work,
+                                   hipStream_t s);
+
+hipError_t eval_points(const double* x, const double* W, int64_t ne, int M, const double* xq,
+                       int64_t P, double* uq, int64_t* elem, hipStream_t s);
+
+hipError_t fp64_probe(double* out, int blocks, int iters, int use_mfma, hipStream_t s);
+
+}  // namespace lssvr

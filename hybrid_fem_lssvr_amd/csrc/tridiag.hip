@@ -1,0 +1,238 @@
+// Device tridiagonal solve for the assembled P1 system with Dirichlet data on
+// both end dofs -- `enforce(A, b, D=basis.get_dofs())` + `solve(A, b)`
+// (Dual.py:129-130).  SURVEY.md section 8(f) "next-1".
+//
+// Algorithm: recursive substructuring (static condensation).  Every kLc-th
+// unknown is a separator; one thread condenses the kLc-1 unknowns between two
+// separators onto them (two O(1)-state sweeps, nothing stored), the separators
+// form a tridiagonal system kLc times smaller, which is solved the same way
+// until <= kBase unknowns remain (one thread, Thomas).  Going back up, each thread
+// re-solves its chunk with the now-known separator values.  The P1 matrix is
+// SPD, so no pivoting is needed at any level (Schur complements of SPD are SPD).
+#include "lssvr_device.hpp"
+#include "lssvr_kernels.hpp"
+
+namespace lssvr {
+
+constexpr int kLc = 32;
+constexpr int64_t kBase = 512;
+
+// row i: lo[i] x[i-1] + d[i] x[i] + up[i] x[i+1] = r[i] - [i==0] bl[0]*u0 - [i==m-1] br[0]*u1
+struct TriSys {
+  const double* lo;
+  const double* d;
+  const double* up;
+  const double* r;
+  const double* bl;
+  const double* br;
+  double u0, u1;
+  int64_t m;
+};
+
+__device__ __forceinline__ double lo_at(const TriSys& s, int64_t i) { return i == 0 ? 0.0 : s.lo[i]; }
+__device__ __forceinline__ double up_at(const TriSys& s, int64_t i) {
+  return i == s.m - 1 ? 0.0 : s.up[i];
+}
+__device__ __forceinline__ double r_at(const TriSys& s, int64_t i) {
+  double v = s.r[i];
+  if (i == 0 && s.bl) v -= s.bl[0] * s.u0;
+  if (i == s.m - 1 && s.br) v -= s.br[0] * s.u1;
+  return v;
+}
+
+struct ChunkEnds {
+  double yF, vF, wF, yL, vL, wL;
+};
+
+// x_interior = y + v * x_{left separator} + w * x_{right separator}; only the values
+// at the first and last interior unknown are needed for the reduced system.
+__global__ __launch_bounds__(kBlock) void tri_condense_kernel(TriSys s, int64_t nc,
+                                                               ChunkEnds* __restrict__ ends) {
+  const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (j >= nc) return;
+  const int64_t b = j * kLc;
+  const int64_t e = (b + kLc - 1 < s.m) ? b + kLc - 1 : s.m;   // interior = [b, e)
+  ChunkEnds c;
+  {  // downward sweep -> values at the last interior unknown
+    double den = s.d[b];
+    double cp = up_at(s, b) / den;
+    double y = r_at(s, b) / den;
+    double v = -lo_at(s, b) / den;
+    for (int64_t i = b + 1; i < e; ++i) {
+      const double l = s.lo[i];
+      den = s.d[i] - l * cp;
+      cp = up_at(s, i) / den;
+      y = (r_at(s, i) - l * y) / den;
+      v = (-l * v) / den;
+    }
+    c.yL = y;
+    c.vL = v;
+    c.wL = -cp;               // rhs -up[e-1] e_last  ->  -up[e-1]/den_last
+  }
+  {  // upward sweep -> values at the first interior unknown
+    double den = s.d[e - 1];
+    double bp = lo_at(s, e - 1) / den;
+    double y = r_at(s, e - 1) / den;
+    double w = -up_at(s, e - 1) / den;
+    for (int64_t i = e - 2; i >= b; --i) {
+      const double u = s.up[i];
+      den = s.d[i] - u * bp;
+      bp = lo_at(s, i) / den;
+      y = (r_at(s, i) - u * y) / den;
+      w = (-u * w) / den;
+    }
+    c.yF = y;
+    c.wF = w;
+    c.vF = -bp;
+  }
+  ends[j] = c;
+}
+
+// separator j sits at p = j*kLc + kLc-1, between chunk j (left) and chunk j+1 (right)
+__global__ __launch_bounds__(kBlock) void tri_reduce_kernel(TriSys s, int64_t ns, int64_t nc,
+                                                             const ChunkEnds* __restrict__ ends,
+                                                             double* __restrict__ LO,
+                                                             double* __restrict__ D,
+                                                             double* __restrict__ UP,
+                                                             double* __restrict__ R) {
+  const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (j >= ns) return;
+  const int64_t p = j * kLc + kLc - 1;
+  const double l = s.lo[p];
+  const double u = up_at(s, p);
+  const ChunkEnds cl = ends[j];
+  double dd = s.d[p] + l * cl.wL;
+  double rr = r_at(s, p) - l * cl.yL;
+  double uu = 0.0;
+  if (j + 1 < nc) {
+    const ChunkEnds cr = ends[j + 1];
+    dd += u * cr.vF;
+    rr -= u * cr.yF;
+    uu = u * cr.wF;
+  }
+  LO[j] = l * cl.vL;
+  D[j] = dd;
+  UP[j] = uu;
+  R[j] = rr;
+}
+
+// re-solve every chunk with its separator values known; x (length m) receives the
+// whole level's solution.  cp: scratch of length m.
+__global__ __launch_bounds__(kBlock) void tri_expand_kernel(TriSys s, int64_t ns, int64_t nc,
+                                                             const double* __restrict__ X,
+                                                             double* __restrict__ x,
+                                                             double* __restrict__ cp) {
+  const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (j >= nc) return;
+  const int64_t b = j * kLc;
+  const int64_t e = (b + kLc - 1 < s.m) ? b + kLc - 1 : s.m;
+  const double xl = j > 0 ? X[j - 1] : 0.0;
+  const double xr = j < ns ? X[j] : 0.0;
+  double den = s.d[b];
+  double rb = r_at(s, b) - lo_at(s, b) * xl;
+  if (e - 1 == b) rb -= up_at(s, b) * xr;
+  double c = up_at(s, b) / den;
+  double y = rb / den;
+  cp[b] = c;
+  x[b] = y;
+  for (int64_t i = b + 1; i < e; ++i) {
+    const double l = s.lo[i];
+    double ri = r_at(s, i);
+    if (i == e - 1) ri -= up_at(s, i) * xr;
+    den = s.d[i] - l * c;
+    c = up_at(s, i) / den;
+    y = (ri - l * y) / den;
+    cp[i] = c;
+    x[i] = y;
+  }
+  double xn = y;
+  for (int64_t i = e - 2; i >= b; --i) {
+    xn = x[i] - cp[i] * xn;
+    x[i] = xn;
+  }
+  if (j < ns) x[j * kLc + kLc - 1] = xr;
+}
+
+__global__ void tri_base_kernel(TriSys s, double* __restrict__ x, double* __restrict__ cp) {
+  if (blockIdx.x != 0 || threadIdx.x != 0 || s.m <= 0) return;
+  double den = s.d[0];
+  double c = up_at(s, 0) / den;
+  double y = r_at(s, 0) / den;
+  cp[0] = c;
+  x[0] = y;
+  for (int64_t i = 1; i < s.m; ++i) {
+    const double l = s.lo[i];
+    den = s.d[i] - l * c;
+    c = up_at(s, i) / den;
+    y = (r_at(s, i) - l * y) / den;
+    cp[i] = c;
+    x[i] = y;
+  }
+  double xn = y;
+  for (int64_t i = s.m - 2; i >= 0; --i) {
+    xn = x[i] - cp[i] * xn;
+    x[i] = xn;
+  }
+}
+
+__global__ void tri_ends_kernel(double* u, int64_t ne, double u0, double u1) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    u[0] = u0;
+    u[ne] = u1;
+  }
+}
+
+// workspace (in doubles): per level cp[m] + ends[6*nc] + reduced LO,D,UP,R,X [5*ns]
+static int64_t level_doubles(int64_t m) {
+  int64_t tot = 0;
+  while (m > kBase) {
+    const int64_t nc = (m + kLc - 1) / kLc, ns = m / kLc;
+    tot += m + 6 * nc + 5 * ns + 16;
+    m = ns;
+  }
+  return tot + m + 16;
+}
+
+int64_t tridiag_work_bytes(int64_t ne) {
+  const int64_t m = ne > 1 ? ne - 1 : 0;
+  return 8 * level_doubles(m) + 256;
+}
+
+static hipError_t solve_level(const TriSys& s, double* x, double* work, hipStream_t st) {
+  if (s.m <= 0) return hipSuccess;
+  if (s.m <= kBase) {
+    hipLaunchKernelGGL(tri_base_kernel, dim3(1), dim3(64), 0, st, s, x, work);
+    return hipGetLastError();
+  }
+  const int64_t nc = (s.m + kLc - 1) / kLc, ns = s.m / kLc;
+  double* cp = work;
+  ChunkEnds* ends = reinterpret_cast<ChunkEnds*>(cp + s.m);
+  double* LO = reinterpret_cast<double*>(ends + nc);
+  double* D = LO + ns;
+  double* UP = D + ns;
+  double* R = UP + ns;
+  double* X = R + ns;
+  double* next = X + ns + 16;
+  const unsigned gc = (unsigned)((nc + kBlock - 1) / kBlock);
+  const unsigned gs = (unsigned)((ns + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(tri_condense_kernel, dim3(gc), dim3(kBlock), 0, st, s, nc, ends);
+  hipLaunchKernelGGL(tri_reduce_kernel, dim3(gs), dim3(kBlock), 0, st, s, ns, nc, ends, LO, D, UP, R);
+  TriSys r{LO, D, UP, R, nullptr, nullptr, 0.0, 0.0, ns};
+  hipError_t err = solve_level(r, X, next, st);
+  if (err != hipSuccess) return err;
+  hipLaunchKernelGGL(tri_expand_kernel, dim3(gc), dim3(kBlock), 0, st, s, ns, nc, X, x, cp);
+  return hipGetLastError();
+}
+
+hipError_t tridiag_dirichlet_solve(const double* diag, const double* off, const double* load,
+                                   int64_t ne, double u0, double u1, double* u, void* work,
+                                   hipStream_t st) {
+  hipLaunchKernelGGL(tri_ends_kernel, dim3(1), dim3(64), 0, st, u, ne, u0, u1);
+  const int64_t m = ne - 1;
+  if (m <= 0) return hipGetLastError();
+  // interior unknown k <-> node k+1: lo = off[k], d = diag[k+1], up = off[k+1], r = load[k+1]
+  TriSys s{off, diag + 1, off + 1, load + 1, off, off + (ne - 1), u0, u1, m};
+  return solve_level(s, u + 1, reinterpret_cast<double*>(work), st);
+}
+
+}  // namespace lssvr

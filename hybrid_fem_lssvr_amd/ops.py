@@ -1,0 +1,243 @@
+"""Device operators: thin, typed wrappers over the C ABI.
+
+PyTorch-ROCm tensors are used as device buffers only (``data_ptr()`` + the
+current HIP stream); all arithmetic happens in the hand-written gfx950 kernels
+behind ``liblssvr_hip.so``.  Every function requires float64 CUDA tensors and
+raises otherwise -- there is no CPU path.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import _capi
+from ._capi import RHS_ARRAY, RHS_SIN, SOLVER_DUAL, SOLVER_PRIMAL
+
+POISSON_AMP = float(math.pi ** 2)     # Dual.py:12  np.pi**2
+POISSON_OMEGA = float(math.pi)
+
+
+def _dev(t, name, dtype=torch.float64):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor device buffer, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: must live in MI355X device memory (got {t.device}); "
+                           "the HIP path has no CPU fallback")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+    return t
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream(stream):
+    if stream is None:
+        return torch.cuda.current_stream().cuda_stream
+    if isinstance(stream, torch.cuda.Stream):
+        return stream.cuda_stream
+    return int(stream)
+
+
+def enhance(x, u, M, gamma, n_colloc=12, *, rhs=(POISSON_AMP, POISSON_OMEGA), rhs_values=None,
+            elem_offset=0, ne_global=None, global_domain=None, bc=(0.0, 0.0),
+            solver=SOLVER_PRIMAL, out=None, status=None, fail_count=None, stream=None):
+    """``solve_lssvr_subproblems`` (Dual.py:139-169) for the shard (x, u).
+
+    x, u: float64[ne+1] device tensors.  Returns (W float64[ne, M], status int32[ne]).
+    ``rhs`` = (amp, omega) evaluates f = amp*sin(omega*x) in-kernel; ``rhs_values``
+    float64[ne, n_colloc] (f tabulated at ``colloc_points``) overrides it.
+    """
+    lib = _capi.load()
+    _dev(x, "x")
+    _dev(u, "u")
+    if x.numel() != u.numel() or x.dim() != 1:
+        raise ValueError("x and u must be 1-D with equal length ne+1")
+    ne = x.numel() - 1
+    if ne < 0:
+        raise ValueError("need at least one node")
+    if ne_global is None:
+        ne_global = elem_offset + ne
+    if global_domain is None:
+        if ne == 0:
+            global_domain = (0.0, 0.0)
+        else:
+            ends = torch.stack([x[0], x[-1]]).cpu()
+            global_domain = (float(ends[0]), float(ends[1]))
+    if out is None:
+        out = torch.empty((ne, M), dtype=torch.float64, device=x.device)
+    else:
+        _dev(out, "out")
+        if out.numel() != ne * M:
+            raise ValueError("out must hold ne*M doubles")
+    if status is None:
+        status = torch.empty((ne,), dtype=torch.int32, device=x.device)
+    else:
+        _dev(status, "status", torch.int32)
+    if fail_count is not None:
+        _dev(fail_count, "fail_count", torch.int32)
+    if rhs_values is not None:
+        _dev(rhs_values, "rhs_values")
+        if rhs_values.numel() != ne * n_colloc:
+            raise ValueError("rhs_values must hold ne*n_colloc doubles")
+        rhs_id, params = RHS_ARRAY, None
+    else:
+        rhs_id, params = RHS_SIN, _capi.rhs_params(*rhs)
+    rc = lib.lssvr_enhance(_ptr(x), _ptr(u), ne, int(elem_offset), int(ne_global),
+                           float(global_domain[0]), float(global_domain[1]),
+                           float(bc[0]), float(bc[1]), int(M), int(n_colloc), float(gamma),
+                           rhs_id, params, _ptr(rhs_values), int(solver),
+                           _ptr(out), _ptr(status), _ptr(fail_count), _stream(stream))
+    _capi.check(rc, "lssvr_enhance")
+    return out, status
+
+
+def enhance_varcoef(x, u, M, gamma, n_colloc, a_values, da_values, rhs_values, *, elem_offset=0,
+                    ne_global=None, global_domain=None, bc=(0.0, 0.0), out=None, status=None,
+                    fail_count=None, stream=None):
+    """BASELINE config 5: rows -a (2/h)^2 L'' - a' (2/h) L' (no reference counterpart)."""
+    lib = _capi.load()
+    _dev(x, "x")
+    _dev(u, "u")
+    ne = x.numel() - 1
+    for t, nm in ((a_values, "a_values"), (da_values, "da_values"), (rhs_values, "rhs_values")):
+        _dev(t, nm)
+        if t.numel() != ne * n_colloc:
+            raise ValueError(f"{nm} must hold ne*n_colloc doubles")
+    if ne_global is None:
+        ne_global = elem_offset + ne
+    if global_domain is None:
+        ends = torch.stack([x[0], x[-1]]).cpu()
+        global_domain = (float(ends[0]), float(ends[1]))
+    if out is None:
+        out = torch.empty((ne, M), dtype=torch.float64, device=x.device)
+    if status is None:
+        status = torch.empty((ne,), dtype=torch.int32, device=x.device)
+    rc = lib.lssvr_enhance_varcoef(_ptr(x), _ptr(u), ne, int(elem_offset), int(ne_global),
+                                   float(global_domain[0]), float(global_domain[1]),
+                                   float(bc[0]), float(bc[1]), int(M), int(n_colloc), float(gamma),
+                                   _ptr(a_values), _ptr(da_values), _ptr(rhs_values),
+                                   _ptr(out), _ptr(status), _ptr(fail_count), _stream(stream))
+    _capi.check(rc, "lssvr_enhance_varcoef")
+    return out, status
+
+
+def colloc_points(x, n_colloc, *, stream=None):
+    """``np.linspace(x[e], x[e+1], n)`` for every element (Dual.py:40) -> float64[ne, n]."""
+    lib = _capi.load()
+    _dev(x, "x")
+    ne = x.numel() - 1
+    xc = torch.empty((ne, n_colloc), dtype=torch.float64, device=x.device)
+    _capi.check(lib.lssvr_colloc_points(_ptr(x), ne, int(n_colloc), _ptr(xc), _stream(stream)),
+                "lssvr_colloc_points")
+    return xc
+
+
+def quad_points(x, nquad=2, *, stream=None):
+    lib = _capi.load()
+    _dev(x, "x")
+    ne = x.numel() - 1
+    xq = torch.empty((ne, nquad), dtype=torch.float64, device=x.device)
+    _capi.check(lib.lssvr_quad_points(_ptr(x), ne, int(nquad), _ptr(xq), _stream(stream)),
+                "lssvr_quad_points")
+    return xq
+
+
+def p1_assemble(x, nquad=2, *, rhs=(POISSON_AMP, POISSON_OMEGA), rhs_quad=None, a_quad=None,
+                want_local=False, out=None, stream=None):
+    """Element-local P1 stiffness/load and the assembled tridiagonal bands
+    (Dual.py:117-128).  Returns dict(diag[ne+1], off[ne], load[ne+1][, kloc, floc])."""
+    lib = _capi.load()
+    _dev(x, "x")
+    ne = x.numel() - 1
+    dev = x.device
+    if out is None:
+        out = {
+            "diag": torch.empty(ne + 1, dtype=torch.float64, device=dev),
+            "off": torch.empty(ne, dtype=torch.float64, device=dev),
+            "load": torch.empty(ne + 1, dtype=torch.float64, device=dev),
+        }
+        if want_local:
+            out["kloc"] = torch.empty(ne, dtype=torch.float64, device=dev)
+            out["floc"] = torch.empty((ne, 2), dtype=torch.float64, device=dev)
+    if rhs_quad is not None:
+        _dev(rhs_quad, "rhs_quad")
+        if rhs_quad.numel() != ne * nquad:
+            raise ValueError("rhs_quad must hold ne*nquad doubles")
+        rhs_id, params = RHS_ARRAY, None
+    else:
+        rhs_id, params = RHS_SIN, _capi.rhs_params(*rhs)
+    if a_quad is not None:
+        _dev(a_quad, "a_quad")
+    rc = lib.lssvr_p1_assemble(_ptr(x), ne, int(nquad), rhs_id, params, _ptr(rhs_quad),
+                               _ptr(a_quad), _ptr(out["diag"]), _ptr(out["off"]),
+                               _ptr(out["load"]), _ptr(out.get("kloc")), _ptr(out.get("floc")),
+                               _stream(stream))
+    _capi.check(rc, "lssvr_p1_assemble")
+    return out
+
+
+def tridiag_dirichlet_solve(diag, off, load, u0=0.0, u1=0.0, *, out=None, work=None, stream=None):
+    """``enforce`` + ``solve`` (Dual.py:129-130) on the assembled bands -> u[ne+1]."""
+    lib = _capi.load()
+    _dev(diag, "diag")
+    _dev(off, "off")
+    _dev(load, "load")
+    ne = off.numel()
+    if diag.numel() != ne + 1 or load.numel() != ne + 1:
+        raise ValueError("band lengths must be ne+1, ne, ne+1")
+    if out is None:
+        out = torch.empty(ne + 1, dtype=torch.float64, device=diag.device)
+    nbytes = lib.lssvr_tridiag_work_bytes(ne)
+    if work is None or work.numel() * work.element_size() < nbytes:
+        work = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=diag.device)
+    rc = lib.lssvr_tridiag_dirichlet_solve(_ptr(diag), _ptr(off), _ptr(load), ne, float(u0),
+                                           float(u1), _ptr(out), _ptr(work), _stream(stream))
+    _capi.check(rc, "lssvr_tridiag_dirichlet_solve")
+    return out
+
+
+def evaluate(x, W, xq, *, want_elem=True, stream=None):
+    """``evaluate_solution`` (Dual.py:176-203) -> (u float64[P], elem int64[P] | None)."""
+    lib = _capi.load()
+    _dev(x, "x")
+    _dev(W, "W")
+    _dev(xq, "xq")
+    ne = x.numel() - 1
+    if W.dim() != 2 or W.shape[0] != ne:
+        raise ValueError("W must be [ne, M]")
+    M = W.shape[1]
+    P = xq.numel()
+    uq = torch.empty(P, dtype=torch.float64, device=x.device)
+    elem = torch.empty(P, dtype=torch.int64, device=x.device) if want_elem else None
+    rc = lib.lssvr_eval(_ptr(x), _ptr(W), ne, int(M), _ptr(xq), P, _ptr(uq), _ptr(elem),
+                        _stream(stream))
+    _capi.check(rc, "lssvr_eval")
+    return uq, elem
+
+
+def fp64_probe(blocks=4096, iters=4096, use_mfma=False, *, device="cuda:0", reps=5):
+    """Measured FP64 FMA (or f64 MFMA) rate in TFLOP/s -- the roofline's compute peak."""
+    lib = _capi.load()
+    out = torch.empty(blocks * 256, dtype=torch.float64, device=device)
+    st = _stream(None)
+    _capi.check(lib.lssvr_fp64_probe(_ptr(out), blocks, iters, int(use_mfma), st), "probe")
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    best = float("inf")
+    for _ in range(reps):
+        e0.record()
+        _capi.check(lib.lssvr_fp64_probe(_ptr(out), blocks, iters, int(use_mfma), st), "probe")
+        e1.record()
+        e1.synchronize()
+        best = min(best, e0.elapsed_time(e1) * 1e-3)
+    if use_mfma:
+        flops = 4.0 * 2048.0 * iters * blocks * 4     # 4 MFMAs/iter/wave, 16x16x4x2 flop, 4 waves/block
+    else:
+        flops = 2.0 * 8.0 * iters * blocks * 256
+    return flops / best / 1e12

@@ -1,0 +1,180 @@
+/*
+ * lssvr_hip.h -- C ABI of the MI355X (gfx950) per-element LSSVR enhancement path.
+ *
+ * The reference (maryambabaei/hybrid-FEM-LSSVR) is pure Python and has no FFI; the
+ * "reference interface" each entry point replaces is therefore a Python call
+ * site in /root/reference/1D-Possion/Hybrid-FEM-LSSVR-Dual.py ("Dual.py").  The
+ * ctypes binding a maintainer adds is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless its name ends in _host;
+ *   - the caller owns every buffer; the library allocates nothing and keeps no
+ *     state besides a thread-local last-error string;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL =
+ *     the default stream) and is safe to capture in a hipGraph;
+ *   - return value: 0 = launched, <0 = argument error (see lssvr_last_error());
+ *   - all floating point is IEEE binary64; element/node indices are int64.
+ *   - element e of a mesh shard has end points x[e], x[e+1] and nodal values
+ *     u[e], u[e+1] (Dual.py:143-147: element i <-> nodes (i, i+1)).
+ */
+#ifndef LSSVR_HIP_H
+#define LSSVR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LSSVR_ABI_VERSION 1
+
+/* error codes */
+#define LSSVR_OK              0
+#define LSSVR_ERR_NULL      (-1)  /* a required pointer is NULL                   */
+#define LSSVR_ERR_SIZE      (-2)  /* ne / P / n_colloc out of range               */
+#define LSSVR_ERR_DEGREE    (-3)  /* M outside the supported range                */
+#define LSSVR_ERR_RHS       (-4)  /* unknown rhs_id or missing rhs data           */
+#define LSSVR_ERR_SOLVER    (-5)  /* unknown solver_id                            */
+#define LSSVR_ERR_LAUNCH    (-6)  /* hipLaunch / runtime error                    */
+#define LSSVR_ERR_QUAD      (-7)  /* unsupported quadrature order                 */
+
+/* right-hand side f(x) of -u'' = f (Dual.py:11-12 `poisson_rhs`, passed as the
+ * callable `rhs_func` at Dual.py:20,157).  A Python callable cannot cross the
+ * ABI, so f is either tabulated by the host facade or named: */
+#define LSSVR_RHS_ARRAY  0  /* rhs_values[e*n_colloc + k] = f(x_k of element e)   */
+#define LSSVR_RHS_SIN    1  /* f(x) = p[0] * sin(p[1] * x), rounded like numpy's
+                               `amp * np.sin(omega * x)`; Poisson: p = {pi^2, pi} */
+
+/* per-element solver */
+#define LSSVR_SOLVER_PRIMAL 0 /* BC-eliminated primal normal equations, (M-2) SPD,
+                                 Jacobi-scaled Cholesky (default; <=1e-15 of the exact
+                                 minimiser on every BASELINE config)              */
+#define LSSVR_SOLVER_DUAL   1 /* north_star's dual Gram form, (n+2) system, equilibrated
+                                 LU with partial pivoting (accuracy-gated) */
+
+/* per-element status written to status[e] */
+#define LSSVR_ST_OK        0
+#define LSSVR_ST_FALLBACK  1  /* factorisation broke down / non-finite: the element got
+                                 the linear interpolant of (g_l, g_r) -- Dual.py:164-169 */
+
+/* ABI version, == LSSVR_ABI_VERSION of the header the library was built from. */
+int lssvr_version(void);
+
+/* Message for the last <0 return on this thread ("" if none). */
+const char* lssvr_last_error(void);
+
+/*
+ * lssvr_enhance -- the hot path.  Replaces the serial loop
+ * `solve_lssvr_subproblems` (Dual.py:139-169) and every `lssvr_primal` call in it
+ * (Dual.py:20-98): one independent QP per element, solved in closed form.
+ *
+ *   x[ne+1], u[ne+1]  node coordinates / FEM nodal values of this shard
+ *                     (Dual.py:144-147; fem_nodes / fem_values, Dual.py:134-135)
+ *   ne                elements in this shard (>= 0; 0 is a no-op)
+ *   elem_offset       global index of the shard's first element, ne_global = total
+ *                     elements: element is_left/is_right_boundary iff its global
+ *                     index is 0 / ne_global-1 (Dual.py:150-151)
+ *   gxmin, gxmax      global_domain (Dual.py:101,161); the Dirichlet value bc_left /
+ *                     bc_right replaces u on a boundary element only if its end
+ *                     point == gxmin / gxmax exactly (Dual.py:65,72)
+ *   M                 number of Legendre coefficients (`lssvr_M`, Dual.py:47), >= 2
+ *   n_colloc          collocation points per element, end points included, >= 2
+ *                     (hard-coded 12 at Dual.py:40)
+ *   gamma             `lssvr_gamma` (Dual.py:49)
+ *   rhs_id/rhs_params/rhs_values   see LSSVR_RHS_* (rhs_params is a HOST pointer)
+ *   W[ne*M]           out: row e = Legendre coefficients of element e on domain
+ *                     [x[e], x[e+1]], window [-1,1] (`Legendre(res.x[:M], domain)`,
+ *                     Dual.py:95)
+ *   status[ne]        out (may be NULL): LSSVR_ST_*
+ *   fail_count        in/out (may be NULL): device int32, incremented once per
+ *                     fallback element (the reference prints per element instead,
+ *                     Dual.py:165)
+ */
+int lssvr_enhance(const double* x, const double* u, int64_t ne,
+                  int64_t elem_offset, int64_t ne_global,
+                  double gxmin, double gxmax, double bc_left, double bc_right,
+                  int M, int n_colloc, double gamma,
+                  int rhs_id, const double* rhs_params_host, const double* rhs_values,
+                  int solver_id,
+                  double* W, int32_t* status, int32_t* fail_count, void* stream);
+
+/*
+ * lssvr_enhance_varcoef -- BASELINE config 5, -(a u')' = f (no reference
+ * counterpart: Dual.py:44,119 hard-code -u'').  PDE row k of element e is
+ *   -a_k (2/h)^2 L_p''(t_k) - da_k (2/h) L_p'(t_k),
+ * with a_values/da_values/rhs_values tabulated at the collocation points
+ * ([ne*n_colloc], row-major per element).  Other arguments as lssvr_enhance.
+ */
+int lssvr_enhance_varcoef(const double* x, const double* u, int64_t ne,
+                          int64_t elem_offset, int64_t ne_global,
+                          double gxmin, double gxmax, double bc_left, double bc_right,
+                          int M, int n_colloc, double gamma,
+                          const double* a_values, const double* da_values,
+                          const double* rhs_values,
+                          double* W, int32_t* status, int32_t* fail_count, void* stream);
+
+/*
+ * lssvr_colloc_points -- x_k of every element exactly as `np.linspace(xmin, xmax, n)`
+ * produces them (Dual.py:40): xc[e*n + k] = fl(fl(k*step)+x[e]), last = x[e+1].
+ * Lets the host tabulate an arbitrary `rhs_func` for LSSVR_RHS_ARRAY.
+ */
+int lssvr_colloc_points(const double* x, int64_t ne, int n_colloc, double* xc, void* stream);
+
+/*
+ * lssvr_p1_assemble -- element-local P1 stiffness and load and their scatter to
+ * the global tridiagonal system.  Replaces `laplace.assemble(basis)` /
+ * `load.assemble(basis)` (Dual.py:117-128) for ElementLineP1 on a MeshLine:
+ *   k_e = abar_e/h_e [[1,-1],[-1,1]],  f_e[j] = sum_q w_q h_e f(x_q) phi_j(xi_q),
+ * Gauss-Legendre with `nquad` points per element (scikit-fem's default for P1 is
+ * 2).  abar_e = quadrature mean of a (1 when a_quad is NULL).
+ *   rhs_id = LSSVR_RHS_SIN: f evaluated in-kernel; LSSVR_RHS_ARRAY:
+ *   rhs_quad[e*nquad + q] = f(x_q).   a_quad[e*nquad + q] likewise (may be NULL).
+ *   diag[ne+1], off[ne], load[ne+1]  out: assembled bands (off[i] couples i,i+1)
+ *   kloc[ne], floc[2*ne]             out, may be NULL: element-local k_e scale and
+ *                                    the two load entries
+ */
+int lssvr_p1_assemble(const double* x, int64_t ne, int nquad,
+                      int rhs_id, const double* rhs_params_host, const double* rhs_quad,
+                      const double* a_quad,
+                      double* diag, double* off, double* load,
+                      double* kloc, double* floc, void* stream);
+
+/*
+ * lssvr_quad_points -- quadrature abscissae xq[e*nquad + q] used by
+ * lssvr_p1_assemble (for host tabulation of rhs / a).
+ */
+int lssvr_quad_points(const double* x, int64_t ne, int nquad, double* xq, void* stream);
+
+/*
+ * lssvr_tridiag_dirichlet_solve -- `enforce(A, b, D=all boundary dofs)` + `solve`
+ * (Dual.py:129-130) for the assembled P1 bands: u[0]=u0, u[ne]=u1, interior by a
+ * device tridiagonal solve.  work: device scratch of lssvr_tridiag_work_bytes(ne).
+ */
+int64_t lssvr_tridiag_work_bytes(int64_t ne);
+int lssvr_tridiag_dirichlet_solve(const double* diag, const double* off, const double* load,
+                                  int64_t ne, double u0, double u1,
+                                  double* u, void* work, void* stream);
+
+/*
+ * lssvr_eval -- `evaluate_solution` (Dual.py:176-203): for each query point the
+ * first element j with x[j] <= xq <= x[j+1] (points on an interior node take the
+ * LEFT element; below/above the mesh -> element 0 / ne-1, polynomial
+ * extrapolation; NaN -> elem -1, value 0), then Clenshaw evaluation in numpy's
+ * operation order (legendre.py `legval`).
+ *   uq[P] out; elem[P] out (may be NULL), int64 element indices.
+ */
+int lssvr_eval(const double* x, const double* W, int64_t ne, int M,
+               const double* xq, int64_t P, double* uq, int64_t* elem, void* stream);
+
+/*
+ * lssvr_fp64_probe -- FP64 FMA throughput microbenchmark used to quote the
+ * roofline peak: runs `iters` dependent-free fused multiply-adds per lane on
+ * `blocks` x 256 threads; out[blocks*256] receives a checksum.  flops = 2 * 8 *
+ * iters * blocks * 256 (8 independent accumulators per lane).
+ */
+int lssvr_fp64_probe(double* out, int blocks, int iters, int use_mfma, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSSVR_HIP_H */

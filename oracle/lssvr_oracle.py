@@ -346,6 +346,74 @@ def enhance_all(nodes, values, M, gamma, n=12, rhs=poisson_rhs, global_domain=No
     return W, status
 
 
+def enhance_all_vec(nodes, values, M, gamma, n=12, rhs=poisson_rhs, global_domain=None,
+                    coef_a=None, coef_da=None, bc_left=0.0, bc_right=0.0, chunk=200000):
+    """Batched float64 primal-KKT solve of every element (same rows as
+    :func:`element_system`, same equilibration as :func:`solve_primal_kkt`); used by
+    the full-size parity tests where the per-element loop is too slow."""
+    nodes = np.asarray(nodes, dtype=np.float64)
+    values = np.asarray(values, dtype=np.float64)
+    ne = len(nodes) - 1
+    if global_domain is None:
+        global_domain = (nodes[0], nodes[-1])
+    W = np.zeros((ne, M))
+    for s0 in range(0, ne, chunk):
+        s1 = min(ne, s0 + chunk)
+        a = nodes[s0:s1]
+        b = nodes[s0 + 1:s1 + 1]
+        gl = values[s0:s1].copy()
+        gr = values[s0 + 1:s1 + 1].copy()
+        if s0 == 0 and a[0] == global_domain[0]:
+            gl[0] = bc_left
+        if s1 == ne and b[-1] == global_domain[1]:
+            gr[-1] = bc_right
+        oldlen = b - a
+        off = (b * -1.0 - a * 1.0) / oldlen
+        scl = 2.0 / oldlen
+        step = oldlen / (n - 1)
+        k = np.arange(n, dtype=np.float64)
+        x = k[None, :] * step[:, None]
+        x = x + a[:, None]
+        x[:, -1] = b
+        t = off[:, None] + scl[:, None] * x
+        m = s1 - s0
+        L = np.zeros((m, n, M)); D1 = np.zeros((m, n, M)); D2 = np.zeros((m, n, M))
+        L[..., 0] = 1.0
+        if M > 1:
+            L[..., 1] = t
+            D1[..., 1] = 1.0
+        for p in range(1, M - 1):
+            L[..., p + 1] = ((2 * p + 1) * t * L[..., p] - p * L[..., p - 1]) / (p + 1)
+            D1[..., p + 1] = D1[..., p - 1] + (2 * p + 1) * L[..., p]
+            D2[..., p + 1] = D2[..., p - 1] + (2 * p + 1) * D1[..., p]
+        if coef_a is None:
+            Ahat = -D2
+        else:
+            Ahat = -(coef_a(x)[..., None] * D2) - (coef_da(x) / scl[:, None])[..., None] * D1
+        ta = off + scl * a
+        tb = off + scl * b
+        Bm = np.zeros((m, 2, M))
+        for row, tt in ((0, ta), (1, tb)):
+            Bm[:, row, 0] = 1.0
+            if M > 1:
+                Bm[:, row, 1] = tt
+            for p in range(1, M - 1):
+                Bm[:, row, p + 1] = ((2 * p + 1) * tt * Bm[:, row, p] - p * Bm[:, row, p - 1]) / (p + 1)
+        f = np.asarray(rhs(x), dtype=np.float64)
+        ftil = f / (scl * scl)[:, None]
+        eps = 1.0 / (float(gamma) * scl ** 4)
+        K = np.zeros((m, M + 2, M + 2))
+        K[:, :M, :M] = np.einsum("ekp,ekq->epq", Ahat, Ahat) + eps[:, None, None] * np.eye(M)[None]
+        K[:, :M, M:] = np.transpose(Bm, (0, 2, 1))
+        K[:, M:, :M] = Bm
+        r = np.zeros((m, M + 2))
+        r[:, :M] = np.einsum("ekp,ek->ep", Ahat, ftil)
+        r[:, M] = gl
+        r[:, M + 1] = gr
+        W[s0:s1] = np.linalg.solve(K, r[..., None])[..., 0][:, :M]
+    return W
+
+
 # --------------------------------------------------------------------------
 # evaluate_solution, Dual.py:176-203
 # --------------------------------------------------------------------------
@@ -428,34 +496,44 @@ def evaluate_solution_vec(nodes, W, xq):
 # --------------------------------------------------------------------------
 # P1 FEM step, Dual.py:110-137 (scikit-fem semantics per SURVEY.md Appendix C)
 # --------------------------------------------------------------------------
-GAUSS2_XI = (0.5 - 0.5 / np.sqrt(3.0), 0.5 + 0.5 / np.sqrt(3.0))
+def gauss_rule01(nquad=2):
+    """Gauss-Legendre rule mapped to [0,1] (scikit-fem's default for P1 is 2 points:
+    xi = 1/2 -+ 1/(2 sqrt 3), w = 1/2 -- SURVEY.md Appendix C)."""
+    xg, wg = np.polynomial.legendre.leggauss(int(nquad))
+    return 0.5 * (1.0 + xg), 0.5 * wg
 
 
-def p1_assemble_local(nodes, rhs=poisson_rhs, coef_a=None):
+def quad_points(nodes, nquad=2):
+    nodes = np.asarray(nodes, dtype=np.float64)
+    xi, _ = gauss_rule01(nquad)
+    a = nodes[:-1]
+    h = nodes[1:] - a
+    return a[:, None] + h[:, None] * xi[None, :]
+
+
+def p1_assemble_local(nodes, rhs=poisson_rhs, coef_a=None, nquad=2):
     """Element-local P1 stiffness and load (Dual.py:117-128).
 
-    k_e = abar_e/h [[1,-1],[-1,1]] (abar_e = 2-point Gauss mean of a, 1 for Poisson;
-    the reference's two minus signs cancel), f_e[k] = sum_q (h/2) f(x_q) phi_k(xi_q)
-    with the 2-point Gauss rule on [0,1].  Returns (kdiag[ne], fl[ne], fr[ne]):
+    k_e = abar_e/h [[1,-1],[-1,1]] (abar_e = quadrature mean of a, 1 for Poisson; the
+    reference's two minus signs cancel), f_e[j] = h sum_q w_q f(x_q) phi_j(xi_q) with
+    the ``nquad``-point Gauss rule on [0,1].  Returns (kdiag[ne], fl[ne], fr[ne]):
     kdiag = abar_e/h, fl/fr = load on the element's left/right node.
     """
     nodes = np.asarray(nodes, dtype=np.float64)
-    a = nodes[:-1]
-    b = nodes[1:]
-    h = b - a
-    x1 = a + h * GAUSS2_XI[0]
-    x2 = a + h * GAUSS2_XI[1]
-    f1 = rhs(x1)
-    f2 = rhs(x2)
-    if coef_a is None:
-        abar = np.ones_like(h)
-    else:
-        abar = 0.5 * (coef_a(x1) + coef_a(x2))
-    kdiag = abar / h
-    hw = 0.5 * h
-    fl = hw * (f1 * (1.0 - GAUSS2_XI[0]) + f2 * (1.0 - GAUSS2_XI[1]))
-    fr = hw * (f1 * GAUSS2_XI[0] + f2 * GAUSS2_XI[1])
-    return kdiag, fl, fr
+    xi, wt = gauss_rule01(nquad)
+    h = nodes[1:] - nodes[:-1]
+    xq = quad_points(nodes, nquad)
+    fq = np.asarray(rhs(xq), dtype=np.float64)
+    sl = np.zeros_like(h)
+    sr = np.zeros_like(h)
+    am = np.zeros_like(h)
+    for k in range(len(xi)):
+        sl = sl + (wt[k] * (1.0 - xi[k])) * fq[:, k]
+        sr = sr + (wt[k] * xi[k]) * fq[:, k]
+        if coef_a is not None:
+            am = am + wt[k] * coef_a(xq[:, k])
+    abar = np.ones_like(h) if coef_a is None else am
+    return abar / h, h * sl, h * sr
 
 
 def p1_scatter(kdiag, fl, fr):
@@ -497,10 +575,32 @@ def thomas_dirichlet(diag, off, load, u0=0.0, u1=0.0):
     return u
 
 
-def fem_p1_solve(nodes, rhs=poisson_rhs, coef_a=None):
+def banded_dirichlet(diag, off, load, u0=0.0, u1=0.0):
+    """Same system as :func:`thomas_dirichlet`, LAPACK banded solve (fast for 1e7 dofs)."""
+    from scipy.linalg import solve_banded
+    n = len(diag)
+    u = np.zeros(n)
+    u[0], u[-1] = u0, u1
+    m = n - 2
+    if m <= 0:
+        return u
+    r = load[1:-1].copy()
+    r[0] -= off[0] * u0
+    r[-1] -= off[-1] * u1
+    ab = np.zeros((3, m))
+    ab[1] = diag[1:-1]
+    ab[0, 1:] = off[1:-1]
+    ab[2, :-1] = off[1:-1]
+    u[1:-1] = solve_banded((1, 1), ab, r)
+    return u
+
+
+def fem_p1_solve(nodes, rhs=poisson_rhs, coef_a=None, nquad=2):
     """``solve_fem`` (Dual.py:110-137) -> nodal values float64[ne+1]."""
-    kdiag, fl, fr = p1_assemble_local(nodes, rhs, coef_a)
+    kdiag, fl, fr = p1_assemble_local(nodes, rhs, coef_a, nquad)
     diag, off, load = p1_scatter(kdiag, fl, fr)
+    if len(diag) > 4096:
+        return banded_dirichlet(diag, off, load)
     return thomas_dirichlet(diag, off, load)
 
 
