@@ -18,6 +18,7 @@ RHS_ARRAY = 0
 RHS_SIN = 1
 SOLVER_PRIMAL = 0
 SOLVER_DUAL = 1
+SOLVER_PRIMAL_WAVE = 2
 ST_OK = 0
 ST_FALLBACK = 1
 

@@ -85,12 +85,14 @@ int lssvr_enhance(const double* x, const double* u, int64_t ne, int64_t elem_off
   }
   a.status = status;
   a.fail_count = fail_count;
-  if (solver_id != LSSVR_SOLVER_PRIMAL && solver_id != LSSVR_SOLVER_DUAL)
+  if (solver_id != LSSVR_SOLVER_PRIMAL && solver_id != LSSVR_SOLVER_DUAL &&
+      solver_id != LSSVR_SOLVER_PRIMAL_WAVE)
     return fail(LSSVR_ERR_SOLVER, "unknown solver_id %d", solver_id);
   if (ne == 0) return LSSVR_OK;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (solver_id == LSSVR_SOLVER_DUAL) return check_launch(lssvr::enhance_dual(a, s), "enhance_dual");
-  if (M <= lssvr::kSmallMaxM) return check_launch(lssvr::enhance_small(a, s), "enhance_small");
+  if (M <= lssvr::kSmallMaxM && solver_id == LSSVR_SOLVER_PRIMAL)
+    return check_launch(lssvr::enhance_small(a, s), "enhance_small");
   return check_launch(lssvr::enhance_large(a, s), "enhance_large");
 }
 

@@ -7,7 +7,7 @@
 namespace lssvr {
 
 constexpr int kSmallMaxM = 14;   // lane-per-element path: M-2 <= 12 register-resident
-constexpr int kLargeMaxM = 34;   // half-wave-per-element path: M-2 <= 32
+constexpr int kLargeMaxM = 33;   // wave-per-element MFMA path: M-2 bubble coefficients + rhs <= 32
 
 struct EnhanceArgs {
   const double* x;

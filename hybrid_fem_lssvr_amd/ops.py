@@ -12,7 +12,7 @@ import math
 import torch
 
 from . import _capi
-from ._capi import RHS_ARRAY, RHS_SIN, SOLVER_DUAL, SOLVER_PRIMAL
+from ._capi import RHS_ARRAY, RHS_SIN, SOLVER_DUAL, SOLVER_PRIMAL, SOLVER_PRIMAL_WAVE  # noqa: F401
 
 POISSON_AMP = float(math.pi ** 2)     # Dual.py:12  np.pi**2
 POISSON_OMEGA = float(math.pi)

@@ -51,6 +51,10 @@ extern "C" {
                                  minimiser on every BASELINE config)              */
 #define LSSVR_SOLVER_DUAL   1 /* north_star's dual Gram form, (n+2) system, equilibrated
                                  LU with partial pivoting (accuracy-gated) */
+#define LSSVR_SOLVER_PRIMAL_WAVE 2 /* same algorithm as PRIMAL, forced onto the
+                                 wave-per-element / f64-MFMA Gram mapping whatever M is
+                                 (PRIMAL picks lane-per-element for M <= 14); for A/B
+                                 measurements of the two mappings */
 
 /* per-element status written to status[e] */
 #define LSSVR_ST_OK        0
@@ -77,7 +81,7 @@ const char* lssvr_last_error(void);
  *   gxmin, gxmax      global_domain (Dual.py:101,161); the Dirichlet value bc_left /
  *                     bc_right replaces u on a boundary element only if its end
  *                     point == gxmin / gxmax exactly (Dual.py:65,72)
- *   M                 number of Legendre coefficients (`lssvr_M`, Dual.py:47), >= 2
+ *   M                 number of Legendre coefficients (`lssvr_M`, Dual.py:47), 2..33
  *   n_colloc          collocation points per element, end points included, >= 2
  *                     (hard-coded 12 at Dual.py:40)
  *   gamma             `lssvr_gamma` (Dual.py:49)

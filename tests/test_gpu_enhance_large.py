@@ -1,0 +1,127 @@
+"""GPU parity tests of the wave-per-element / f64-MFMA mapping (M up to 33)."""
+import numpy as np
+import pytest
+
+from oracle import lssvr_oracle as orc
+from oracle import closed_form_mp as cf
+
+pytestmark = pytest.mark.gpu
+
+TOL_TRUTH = 1e-13
+TOL_REF = 1e-10
+
+
+def _t(a, dev):
+    import torch
+    return torch.as_tensor(np.ascontiguousarray(a), device=dev)
+
+
+def _enhance(dev, nodes, values, M, gamma, n, **kw):
+    import torch
+    from hybrid_fem_lssvr_amd import ops
+    W, st = ops.enhance(_t(nodes, dev), _t(values, dev), M, gamma, n, **kw)
+    torch.cuda.synchronize()
+    return W.cpu().numpy(), st.cpu().numpy()
+
+
+def test_golden_degree32(dev, golden):
+    """BASELINE config 4's element problem (M=33, 64 points) vs the reference's SLSQP
+    output and the 60-digit minimiser (fixture G5)."""
+    g = golden("G5_ne24_M33_n64")
+    ne, M, n, gamma = int(g["ne"]), int(g["M"]), int(g["n"]), float(g["gamma"])
+    nodes = np.linspace(-1.0, 1.0, ne + 1)
+    values = orc.fem_p1_solve(nodes)
+    values[g["elements"]] = g["values_sel"][:, 0]
+    values[g["elements"] + 1] = g["values_sel"][:, 1]
+    W, st = _enhance(dev, nodes, values, M, gamma, n)
+    assert np.all(st == 0)
+    Wsel = W[g["elements"]]
+    assert orc.rel_l2_coef(Wsel, g["coef_truth"]).max() <= TOL_TRUTH
+    assert orc.rel_l2_coef(Wsel, g["coef_ref"]).max() <= TOL_REF
+
+
+@pytest.mark.parametrize("M", [15, 16, 17, 18, 19, 24, 31, 32, 33])
+def test_large_degrees_vs_oracle(dev, M):
+    rng = np.random.default_rng(500 + M)
+    ne = 203
+    nodes = np.cumsum(np.concatenate([[-0.7], rng.uniform(0.01, 0.08, ne)]))
+    values = np.sin(np.pi * nodes) + 0.01 * rng.standard_normal(ne + 1)
+    n = {15: 16, 16: 31, 17: 32, 18: 33, 19: 40, 24: 64, 31: 65, 32: 96, 33: 64}[M]
+    gd = (nodes[0], nodes[-1])
+    W, st = _enhance(dev, nodes, values, M, 1e4, n, global_domain=gd)
+    assert np.all(st == 0)
+    Wo = orc.enhance_all_vec(nodes, values, M, 1e4, n, global_domain=gd)
+    err = orc.rel_l2_coef(W, Wo)
+    assert err.max() <= 1e-11, (M, err.max())
+    if cf.HAVE_MP:
+        sel = [0, ne // 2, ne - 1]
+        tr = cf.truth_all(nodes, values, M, 1e4, n, orc.poisson_rhs, gd, sel)
+        assert orc.rel_l2_coef(W[sel], tr).max() <= TOL_TRUTH
+
+
+@pytest.mark.parametrize("M", [2, 3, 5, 9, 14])
+def test_wave_mapping_matches_lane_mapping(dev, M):
+    """The two mappings of the same algorithm (solver 0 vs 2) agree to rounding."""
+    from hybrid_fem_lssvr_amd import ops
+    ne, n = 1500, 16
+    nodes = np.linspace(-1, 1, ne + 1)
+    values = orc.fem_p1_solve(nodes)
+    W0, s0 = _enhance(dev, nodes, values, M, 1e4, n)
+    W2, s2 = _enhance(dev, nodes, values, M, 1e4, n, solver=ops.SOLVER_PRIMAL_WAVE)
+    assert np.all(s0 == 0) and np.all(s2 == 0)
+    assert orc.rel_l2_coef(W2, W0).max() <= 1e-12
+
+
+def test_boundary_rows_general_recurrence_branch(dev):
+    """|x|/h ~ 1e10 makes t(xmin), t(xmax) miss -1, +1 by ~1e-6, which sends the
+    boundary rows of the wave kernel through the general recurrence instead of the
+    near-one series; both must reproduce the oracle, which mirrors the same float64
+    abscissae (Dual.py:66-75 evaluates u(xmin) through the same mapdomain)."""
+    ne, M, n = 64, 20, 24
+    nodes = 1.0e6 + 1.0e-4 * np.arange(ne + 1)
+    values = np.cos(np.arange(ne + 1) * 0.1)
+    gd = (nodes[0], nodes[-1])
+    W, st = _enhance(dev, nodes, values, M, 1e4, n, global_domain=gd)
+    Wo = orc.enhance_all_vec(nodes, values, M, 1e4, n, global_domain=gd)
+    ok = st == 0
+    assert ok.sum() >= ne - 2
+    assert orc.rel_l2_coef(W[ok], Wo[ok]).max() <= 1e-9
+
+
+def test_full_size_config4_sample(dev):
+    """BASELINE config 4 (1e5 elements, degree 32, 64 points): all elements solved,
+    boundary rows exact, sampled elements vs the 60-digit minimiser."""
+    ne, M, n = 100000, 33, 64
+    nodes = np.linspace(-1, 1, ne + 1)
+    values = orc.fem_p1_solve(nodes)
+    W, st = _enhance(dev, nodes, values, M, 1e4, n)
+    assert np.all(st == 0)
+    sgn = (-1.0) ** np.arange(M)
+    assert np.max(np.abs(W @ sgn - np.concatenate([[0.0], values[1:-1]]))) < 1e-12
+    assert np.max(np.abs(W.sum(1) - np.concatenate([values[1:-1], [0.0]]))) < 1e-12
+    sel = np.array([0, 1, 31337, 50000, 99999])
+    Wo = orc.enhance_all_vec(nodes[:2001], np.r_[values[:2001]], M, 1e4, n, global_domain=(-1.0, 1.0))
+    assert orc.rel_l2_coef(W[:1999], Wo[:1999]).max() <= 1e-11
+    if cf.HAVE_MP:
+        tr = cf.truth_all(nodes, values, M, 1e4, n, orc.poisson_rhs, (-1.0, 1.0), sel)
+        assert orc.rel_l2_coef(W[sel], tr).max() <= TOL_TRUTH
+
+
+def test_fallback_status_large(dev):
+    import torch
+    from hybrid_fem_lssvr_amd import ops
+    ne, M, n = 40, 20, 32
+    nodes = np.linspace(0, 1, ne + 1)
+    nodes[11] = nodes[10]
+    values = np.sin(nodes)
+    values[30] = np.nan
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    W, st = ops.enhance(_t(nodes, dev), _t(values, dev), M, 1e4, n, fail_count=cnt,
+                        global_domain=(0.0, 1.0))
+    torch.cuda.synchronize()
+    st = st.cpu().numpy()
+    W = W.cpu().numpy()
+    assert set(np.nonzero(st)[0]) == {10, 29, 30}
+    assert int(cnt.item()) == 3
+    assert np.allclose(W[10, :2], [0.5 * (values[10] + values[11]), 0.5 * (values[11] - values[10])])
+    assert np.all(W[10, 2:] == 0)
