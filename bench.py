@@ -1,0 +1,304 @@
+#!/usr/bin/env python3
+"""Benchmark of the per-element LSSVR enhancement hot path on MI355X.
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` prints ONE JSON
+line on rank 0.  For N > 1 it is launched through ``torch.distributed.run`` with one
+rank per GPU (RCCL).
+
+Metric  : LSSVR-enhanced elements/s (BASELINE.json ``metric``).
+Step    : one pass of the hot path over one batch of elements that is already
+          resident in HBM: element-local P1 stiffness/load assembly (Dual.py:117-128)
+          + the per-element Gram + solve (Dual.py:139-169); at N > 1 also the
+          chunk-overlapped RCCL all-gather that stitches the coefficient rows.
+Workload: BASELINE config 2 -- degree 8 (M = 9), 16 collocation points, gamma = 1e4,
+          1e5 P1 elements per GPU -- on the wide domain [-N, N] with h = 1/12
+          (100 008 elements per GPU; SURVEY.md finding 5: on [-1,1] the reference's own
+          SLSQP loop stops converging above ~5e4 elements, so the CPU baseline could
+          not be timed on it; kernel cost does not depend on the domain).
+          ``--domain narrow`` runs exactly 1e5 elements on [-1,1] instead.
+Scaling : weak (per-GPU elements fixed).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+M_DEG8, N_COLLOC, GAMMA = 9, 16, 1.0e4
+NE_WIDE, HALF_WIDE = 100008, 4167.0        # h = 1/12 exactly
+NE_NARROW = 100000
+FP64_PEAK_TFLOPS = 78.6                    # MI355X vector = matrix FP64 peak (SURVEY.md 8(d):
+                                           # 256 CU x 4 SIMD x 32 FLOP/clk x 2.4 GHz); probe below
+HBM_PEAK_GBS = 8000.0
+
+
+def algorithmic_flops(M, n):
+    """SURVEY.md 8(d), primal form: Gram M(M+1)n + A^T f 2Mn + KKT-LU 2/3 (M+2)^3 + 2 (M+2)^2."""
+    return M * (M + 1) * n + 2 * M * n + (2.0 / 3.0) * (M + 2) ** 3 + 2 * (M + 2) ** 2
+
+
+def algorithmic_bytes(M):
+    """node coordinate 8 B + nodal value 8 B + 8 M B of coefficients."""
+    return 16 + 8 * M
+
+
+# ----------------------------------------------------------------------------------------
+# CPU baseline: the reference's own per-element SLSQP loop (oracle restatement, "port")
+# ----------------------------------------------------------------------------------------
+def _cpu_worker(args):
+    os.environ["OMP_NUM_THREADS"] = os.environ["OPENBLAS_NUM_THREADS"] = "1"
+    import numpy as np
+    from oracle import lssvr_oracle as orc
+    nodes, values, elems, ne, gd, seed = args
+    rng = np.random.default_rng(seed)
+    t0 = time.perf_counter()
+    ok = 0
+    for i in elems:
+        j = int(i)
+        _, s = orc.slsqp_element(orc.poisson_rhs, nodes[j], nodes[j + 1], values[j], values[j + 1],
+                                 M_DEG8, GAMMA, N_COLLOC, left=(j == 0), right=(j == ne - 1),
+                                 global_domain=gd, rng=rng)
+        ok += int(s)
+    return len(elems), ok, time.perf_counter() - t0
+
+
+def cpu_baseline(nodes_host, values_host, gd, per_core=8):
+    """Times the SLSQP loop on a bounded sample of the same mesh with every host core the
+    box gives us (one process per core, like N copies of the single-threaded reference)."""
+    import multiprocessing as mp
+    import numpy as np
+    cores = max(1, min(len(os.sched_getaffinity(0)), 16))
+    ne = len(nodes_host) - 1
+    sample = np.linspace(0, ne - 1, cores * per_core).astype(np.int64)
+    parts = np.array_split(sample, cores)
+    jobs = [(nodes_host, values_host, p, ne, gd, 1000 + k) for k, p in enumerate(parts)]
+    ctx = mp.get_context("fork")
+    t0 = time.perf_counter()
+    with ctx.Pool(cores) as pool:
+        res = pool.map(_cpu_worker, jobs)
+    wall = time.perf_counter() - t0
+    done = sum(r[0] for r in res)
+    conv = sum(r[1] for r in res)
+    busy = sum(r[2] for r in res)
+    return {
+        "value": done / wall,
+        "unit": "elements/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{done} elements evenly spaced through the same {ne}-element mesh, "
+                  f"per-element scipy SLSQP loop (oracle/lssvr_oracle.py::slsqp_element = "
+                  f"Dual.py:20-98), one process per core; {conv}/{done} converged",
+        "single_core_value": done / busy,
+    }
+
+
+# ----------------------------------------------------------------------------------------
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--domain", choices=["wide", "narrow"], default="wide")
+    ap.add_argument("--degree", type=int, default=8)
+    ap.add_argument("--colloc", type=int, default=N_COLLOC)
+    ap.add_argument("--elements", type=int, default=0, help="elements per GPU (0 = config default)")
+    ap.add_argument("--chunks", type=int, default=4, help="all-gather chunks at N > 1")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the stitching all-gather")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from hybrid_fem_lssvr_amd import ops
+    from hybrid_fem_lssvr_amd.distributed import ShardPlan, allgather_rows
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    M = args.degree + 1
+    n = args.colloc
+    if args.domain == "wide":
+        ne_loc = args.elements or NE_WIDE
+        half = ne_loc * world / 24.0                      # h = 1/12
+        lo, hi = -half, half
+    else:
+        ne_loc = args.elements or NE_NARROW
+        lo, hi = -1.0, 1.0
+    plan = ShardPlan(ne_loc * world, world)
+    ne_glob = plan.ne
+    s0, s1 = plan.bounds(rank)
+
+    # synthetic input, resident in HBM before the timed region ----------------------------
+    # nodes of this rank's shard exactly as np.linspace(lo, hi, ne_glob+1) gives them
+    step = (hi - lo) / ne_glob
+    idx = np.arange(s0, s1 + 1, dtype=np.float64)
+    nodes_h = idx * step + lo
+    if s1 == ne_glob:
+        nodes_h[-1] = hi
+    values_h = np.sin(np.pi * nodes_h)                    # nodal values of the exact solution
+    if s0 == 0:
+        values_h[0] = 0.0
+    if s1 == ne_glob:
+        values_h[-1] = 0.0
+    gd = (lo, hi)
+
+    # CPU baseline first: its worker processes are forked before this process touches the
+    # GPU (a forked child of a GPU-initialised process is best avoided on this pool)
+    cpu_res = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline and M == M_DEG8 and n == N_COLLOC:
+        cpu_res = cpu_baseline(nodes_h, values_h, gd)
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    x = torch.as_tensor(nodes_h, device=dev)
+    u = torch.as_tensor(values_h, device=dev)
+    W = torch.empty((plan.max_size, M), dtype=torch.float64, device=dev)
+    status = torch.empty(ne_loc, dtype=torch.int32, device=dev)
+    bands = ops.p1_assemble(x, 2)
+    Wg = torch.empty((ne_glob, M), dtype=torch.float64, device=dev) if world > 1 and not args.no_gather else None
+    gather = world > 1 and not args.no_gather
+
+    def enhance_rows(r0, r1, dst):
+        ops.enhance(x[r0:r1 + 1], u[r0:r1 + 1], M, GAMMA, n, elem_offset=s0 + r0,
+                    ne_global=ne_glob, global_domain=gd, out=dst, status=status[r0:r1])
+
+    # N = 1: the whole step (assembly + enhancement) is one fused launch bound once
+    fused = ops.StepPlan(x, u, M, GAMMA, n, elem_offset=s0, ne_global=ne_glob, global_domain=gd,
+                         bands=bands, out=W[:ne_loc], status=status)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def one_step(i=None):
+        if gather:
+            ops.p1_assemble(x, 2, out=bands)
+            allgather_rows(W, plan, rank, chunks=args.chunks, out=Wg, compute_chunk=enhance_rows)
+        else:
+            fused.launch(st)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(i)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    n_fallback = int(status.sum().item())
+
+    # dominant kernel (the per-element enhancement): launch duration from HIP events that
+    # hipExtLaunchKernelGGL stamps with the dispatch's own begin / end times -- the quantity
+    # rocprofv3 --kernel-trace reports -- over the same launch as in the timed region,
+    # right after it (a plain hipEventRecord pair adds ~4 us of dispatch latency)
+    k_s = sorted(ops.enhance_profiled(x, u, M, GAMMA, n, elem_offset=s0, ne_global=ne_glob,
+                                      global_domain=gd, out=W[:ne_loc], status=status)
+                 for _ in range(min(args.steps, 100)))
+    k_avg = sum(k_s) / len(k_s)
+    k_med = k_s[len(k_s) // 2]
+
+    if rank == 0:
+        total = ne_glob * args.steps
+        flops = algorithmic_flops(M, n)
+        byts = algorithmic_bytes(M)
+        k_dur = max(k_avg, 1e-9)
+        ach_tflops = flops * ne_loc / k_dur / 1e12
+        kernel_name = "enhance_small_kernel<M=%d>" % M if M <= 14 else "enhance_large_kernel"
+        out = {
+            "metric": "LSSVR-enhanced elements/sec, 1D Poisson deg-%d/%d-pt" % (args.degree, n),
+            "value": total / elapsed,
+            "unit": "elements/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": ("1D Poisson, %d P1 elements per GPU on [%g, %g] (h = %s), Legendre degree %d "
+                             "(M = %d), %d collocation points, gamma = 1e4, f = pi^2 sin(pi x) in-kernel; "
+                             "step = element-local P1 assembly + per-element Gram + solve%s"
+                             % (ne_loc, lo, hi, "1/12" if args.domain == "wide" else "2/ne", args.degree,
+                                M, n, " + chunked RCCL all-gather of W" if gather else "")),
+                "elements_per_gpu": ne_loc,
+                "elements_total": ne_glob,
+                "parallelism": "elements sharded contiguously, %d rank(s)" % world,
+                "solver": "primal, BC-eliminated SPD (M-2), Cholesky",
+                "fallback_elements": n_fallback,
+            },
+            "roofline": {
+                "bound": "mfma",
+                "pipe": "FP64 FMA (vector pipe at degree <= 12, f64 MFMA Gram above); on gfx950 the "
+                        "FP64 vector and matrix peaks are the same 78.6 TFLOP/s",
+                "kernel": kernel_name,
+                "achieved": ach_tflops,
+                "peak": FP64_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": ach_tflops / FP64_PEAK_TFLOPS,
+                "flops_per_element": flops,
+                "elements_per_launch": ne_loc,
+                "kernel_us_avg": k_dur * 1e6,
+                "kernel_us_median": k_med * 1e6,
+                "traffic": None,
+            },
+            "roofline_hbm": {
+                "bound": "hbm",
+                "achieved": byts * ne_loc / k_dur / 1e9,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": byts * ne_loc / k_dur / 1e9 / HBM_PEAK_GBS,
+                "bytes_per_element": byts,
+                "traffic": None,
+            },
+        }
+        tf = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tf):
+            try:
+                tr = json.load(open(tf)).get("M%d_n%d_ne%d" % (M, n, ne_loc))
+                if tr:
+                    out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+                    out["roofline_hbm"]["traffic"] = tr["hbm_bytes_per_launch"]
+            except Exception:
+                pass
+        try:
+            out["roofline"]["fp64_fma_probe_tflops"] = round(ops.fp64_probe(8192, 4096, False), 2)
+        except Exception as exc:  # pragma: no cover
+            out["roofline"]["fp64_fma_probe_tflops"] = "failed: %s" % exc
+        if cpu_res is not None:
+            out["cpu_baseline"] = cpu_res
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

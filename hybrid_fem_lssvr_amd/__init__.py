@@ -6,6 +6,18 @@ argument meaning, with the per-element SLSQP loop replaced by hand-written
 gfx950 kernels behind a C ABI (``include/lssvr_hip.h``).
 """
 from . import _capi, ops  # noqa: F401
+from .mesh import LineMesh, P1Basis, as_line_mesh  # noqa: F401
+from .solver import (  # noqa: F401
+    EnhancedSolution,
+    FEMLSSVRPrimalSolver,
+    SinRHS,
+    enhance_elements,
+    lssvr_primal,
+    main_boundary_condition_left,
+    main_boundary_condition_right,
+    poisson_rhs,
+    true_solution,
+)
+from .distributed import ShardPlan, allgather_rows, enhance_sharded  # noqa: F401
 
-__all__ = ["ops"]
 __version__ = "0.1.0"

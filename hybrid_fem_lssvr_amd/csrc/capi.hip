@@ -57,6 +57,17 @@ int fill_enhance_args(lssvr::EnhanceArgs& a, const double* x, const double* u, i
 
 }  // namespace
 
+namespace {
+// shared tail of lssvr_enhance / lssvr_enhance_profiled
+int enhance_dispatch(const lssvr::EnhanceArgs& a, int solver_id, hipStream_t s,
+                     const lssvr::LaunchOpts* o) {
+  if (solver_id == LSSVR_SOLVER_DUAL) return check_launch(lssvr::enhance_dual(a, s, o), "enhance_dual");
+  if (a.M <= lssvr::kSmallMaxM && solver_id == LSSVR_SOLVER_PRIMAL)
+    return check_launch(lssvr::enhance_small(a, s, o), "enhance_small");
+  return check_launch(lssvr::enhance_large(a, s, o), "enhance_large");
+}
+}  // namespace
+
 extern "C" {
 
 int lssvr_version(void) { return LSSVR_ABI_VERSION; }
@@ -89,10 +100,82 @@ int lssvr_enhance(const double* x, const double* u, int64_t ne, int64_t elem_off
       solver_id != LSSVR_SOLVER_PRIMAL_WAVE)
     return fail(LSSVR_ERR_SOLVER, "unknown solver_id %d", solver_id);
   if (ne == 0) return LSSVR_OK;
+  return enhance_dispatch(a, solver_id, reinterpret_cast<hipStream_t>(stream), nullptr);
+}
+
+int lssvr_enhance_profiled(const double* x, const double* u, int64_t ne, int64_t elem_offset,
+                           int64_t ne_global, double gxmin, double gxmax, double bc_left,
+                           double bc_right, int M, int n_colloc, double gamma, int rhs_id,
+                           const double* rhs_params_host, const double* rhs_values, int solver_id,
+                           double* W, int32_t* status, void* stream, float* kernel_ms_host) {
+  if (!kernel_ms_host) return fail(LSSVR_ERR_NULL, "kernel_ms_host must be non-NULL");
+  lssvr::EnhanceArgs a;
+  int rc = fill_enhance_args(a, x, u, ne, elem_offset, ne_global, gxmin, gxmax, bc_left, bc_right,
+                             M, n_colloc, gamma, W);
+  if (rc != LSSVR_OK) return rc;
+  if (ne == 0) return fail(LSSVR_ERR_SIZE, "nothing to profile: ne = 0");
+  a.rhs_id = rhs_id;
+  if (rhs_id == LSSVR_RHS_SIN) {
+    if (!rhs_params_host) return fail(LSSVR_ERR_RHS, "LSSVR_RHS_SIN needs rhs_params = {amp, omega}");
+    a.rhs_amp = rhs_params_host[0];
+    a.rhs_omega = rhs_params_host[1];
+  } else if (rhs_id == LSSVR_RHS_ARRAY) {
+    if (!rhs_values) return fail(LSSVR_ERR_RHS, "LSSVR_RHS_ARRAY needs rhs_values[ne*n_colloc]");
+    a.rhs_values = rhs_values;
+  } else {
+    return fail(LSSVR_ERR_RHS, "unknown rhs_id %d", rhs_id);
+  }
+  a.status = status;
+  if (solver_id != LSSVR_SOLVER_PRIMAL && solver_id != LSSVR_SOLVER_DUAL &&
+      solver_id != LSSVR_SOLVER_PRIMAL_WAVE)
+    return fail(LSSVR_ERR_SOLVER, "unknown solver_id %d", solver_id);
+  lssvr::LaunchOpts o;
+  if (hipEventCreate(&o.start) != hipSuccess || hipEventCreate(&o.stop) != hipSuccess)
+    return fail(LSSVR_ERR_LAUNCH, "hipEventCreate failed");
+  rc = enhance_dispatch(a, solver_id, reinterpret_cast<hipStream_t>(stream), &o);
+  if (rc == LSSVR_OK) {
+    hipError_t e = hipEventSynchronize(o.stop);
+    if (e == hipSuccess) e = hipEventElapsedTime(kernel_ms_host, o.start, o.stop);
+    if (e != hipSuccess) rc = fail(LSSVR_ERR_LAUNCH, "profiled launch: %s", hipGetErrorString(e));
+  }
+  (void)hipEventDestroy(o.start);
+  (void)hipEventDestroy(o.stop);
+  return rc;
+}
+
+int lssvr_step(const double* x, const double* u, int64_t ne, int64_t elem_offset,
+               int64_t ne_global, double gxmin, double gxmax, double bc_left, double bc_right,
+               int M, int n_colloc, double gamma, const double* rhs_params_host, int nquad,
+               double* diag, double* off, double* load, double* W, int32_t* status,
+               int32_t* fail_count, void* stream) {
+  lssvr::EnhanceArgs a;
+  int rc = fill_enhance_args(a, x, u, ne, elem_offset, ne_global, gxmin, gxmax, bc_left, bc_right,
+                             M, n_colloc, gamma, W);
+  if (rc != LSSVR_OK) return rc;
+  if (ne < 1) return fail(LSSVR_ERR_SIZE, "ne = %lld < 1", (long long)ne);
+  if (!diag || !off || !load) return fail(LSSVR_ERR_NULL, "diag, off, load must be non-NULL");
+  if (!rhs_params_host) return fail(LSSVR_ERR_RHS, "rhs_params = {amp, omega} required");
+  if (nquad < 1 || nquad > 5) return fail(LSSVR_ERR_QUAD, "nquad = %d outside [1,5]", nquad);
+  a.rhs_id = LSSVR_RHS_SIN;
+  a.rhs_amp = rhs_params_host[0];
+  a.rhs_omega = rhs_params_host[1];
+  a.status = status;
+  a.fail_count = fail_count;
+  lssvr::P1Args p{};
+  p.x = x;
+  p.ne = ne;
+  p.nquad = nquad;
+  p.rhs_id = LSSVR_RHS_SIN;
+  p.rhs_amp = a.rhs_amp;
+  p.rhs_omega = a.rhs_omega;
+  p.diag = diag;
+  p.off = off;
+  p.load = load;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (solver_id == LSSVR_SOLVER_DUAL) return check_launch(lssvr::enhance_dual(a, s), "enhance_dual");
-  if (M <= lssvr::kSmallMaxM && solver_id == LSSVR_SOLVER_PRIMAL)
-    return check_launch(lssvr::enhance_small(a, s), "enhance_small");
+  if (M <= lssvr::kSmallMaxM) return check_launch(lssvr::step_small(a, p, s), "step_small");
+  // large degree: the enhancement is long enough that a fused launch buys nothing
+  rc = check_launch(lssvr::p1_assemble(p, s), "p1_assemble");
+  if (rc != LSSVR_OK) return rc;
   return check_launch(lssvr::enhance_large(a, s), "enhance_large");
 }
 

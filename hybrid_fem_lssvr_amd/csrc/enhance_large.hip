@@ -354,7 +354,7 @@ static RecTables make_tables() {
   return t;
 }
 
-hipError_t enhance_large(const EnhanceArgs& a, hipStream_t s) {
+hipError_t enhance_large(const EnhanceArgs& a, hipStream_t s, const LaunchOpts* o) {
   if (a.M - 2 + 1 > kLP) return hipErrorInvalidValue;
   static const RecTables tables = make_tables();
   const int64_t npair = (a.ne + 1) / 2;
@@ -363,14 +363,14 @@ hipError_t enhance_large(const EnhanceArgs& a, hipStream_t s) {
   if (blocks > cap) blocks = cap;
   const dim3 grid((unsigned)blocks), block(kWavesPerBlock * 64);
   if (a.a_values)
-    hipLaunchKernelGGL((enhance_large_kernel<LSSVR_RHS_ARRAY, true>), grid, block, 0, s, a, tables);
-  else if (a.rhs_id == LSSVR_RHS_SIN)
-    hipLaunchKernelGGL((enhance_large_kernel<LSSVR_RHS_SIN, false>), grid, block, 0, s, a, tables);
-  else
-    hipLaunchKernelGGL((enhance_large_kernel<LSSVR_RHS_ARRAY, false>), grid, block, 0, s, a, tables);
-  return hipGetLastError();
+    return launch(enhance_large_kernel<LSSVR_RHS_ARRAY, true>, grid, block, s, o, a, tables);
+  if (a.rhs_id == LSSVR_RHS_SIN)
+    return launch(enhance_large_kernel<LSSVR_RHS_SIN, false>, grid, block, s, o, a, tables);
+  return launch(enhance_large_kernel<LSSVR_RHS_ARRAY, false>, grid, block, s, o, a, tables);
 }
 
-hipError_t enhance_dual(const EnhanceArgs&, hipStream_t) { return hipErrorNotSupported; }
+hipError_t enhance_dual(const EnhanceArgs&, hipStream_t, const LaunchOpts*) {
+  return hipErrorNotSupported;
+}
 
 }  // namespace lssvr

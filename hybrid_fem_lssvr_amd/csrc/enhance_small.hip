@@ -11,7 +11,7 @@
 //      r += rho * phi -- the Legendre Gram contraction over collocation points;
 //   4. the two boundary rows L_p(t_a), L_p(t_b), eliminated analytically:
 //      w_{0,1} = d - C v;
-//   5. S = G + eps (I + C^T C), Jacobi scaling, Cholesky, two triangular solves;
+//   5. S = G + eps (I + C^T C), Cholesky, two triangular solves;
 //   6. status / linear-interpolant fallback (Dual.py:164-169).
 // The 256 x M coefficient tile of a workgroup is transposed through LDS so that
 // the store to W[ne, M] (row-major, 8*M B per element) is fully coalesced.
@@ -22,17 +22,18 @@
 // all 64 lanes do useful FP64 work.  Measured numbers: DESIGN.md.
 #include "lssvr_device.hpp"
 #include "lssvr_kernels.hpp"
+#include "lssvr_p1.hpp"
 
 namespace lssvr {
 
 template <int M, int RHS, bool VC>
-__global__ __launch_bounds__(kBlock) void enhance_small_kernel(EnhanceArgs p) {
+__device__ __forceinline__ void enhance_small_body(const EnhanceArgs& p, const unsigned block,
+                                                   double* __restrict__ tile) {
   constexpr int MR = M - 2;
   constexpr int NT = MR * (MR + 1) / 2;
-  __shared__ double tile[kBlock * M];
 
   const int tid = threadIdx.x;
-  const int64_t e = (int64_t)blockIdx.x * kBlock + tid;
+  const int64_t e = (int64_t)block * kBlock + tid;
   double w[M];
   int st = LSSVR_ST_OK;
 #pragma unroll
@@ -131,25 +132,15 @@ __global__ __launch_bounds__(kBlock) void enhance_small_kernel(EnhanceArgs p) {
         rv[i] = fma(eps, fma(C0[i], d0, C1[i] * d1), rv[i]);
       }
 
-      // --- Jacobi scaling + Cholesky (lower, in place; diagonal holds 1/L_jj) ----
+      // --- Cholesky (lower, in place; diagonal holds 1/L_jj).  No diagonal pre-scaling:
+      // Cholesky is invariant under symmetric diagonal scaling up to rounding (measured:
+      // same <=2e-16 distance to the 60-digit minimiser with and without).
+      // A non-positive / non-finite pivot becomes NaN in rsqrt and reaches every later
+      // entry, so the finiteness test on the solution catches a breakdown.
       bool ok = true;
-      double dj[MR];
-#pragma unroll
-      for (int i = 0; i < MR; ++i) {
-        ok = ok && (G[tri(i, i)] > 0.0);
-        dj[i] = rsqrt_newton(G[tri(i, i)]);
-      }
-#pragma unroll
-      for (int i = 0; i < MR; ++i) {
-#pragma unroll
-        for (int j = 0; j <= i; ++j) G[tri(i, j)] *= dj[i] * dj[j];
-        rv[i] *= dj[i];
-      }
 #pragma unroll
       for (int j = 0; j < MR; ++j) {
-        const double piv = G[tri(j, j)];
-        ok = ok && (piv > 0.0) && (piv < 1.0e300);
-        const double linv = rsqrt_newton(piv);
+        const double linv = rsqrt_newton(G[tri(j, j)]);
         G[tri(j, j)] = linv;
 #pragma unroll
         for (int i = j + 1; i < MR; ++i) G[tri(i, j)] *= linv;
@@ -176,19 +167,19 @@ __global__ __launch_bounds__(kBlock) void enhance_small_kernel(EnhanceArgs p) {
         for (int j = i + 1; j < MR; ++j) s = fma(-G[tri(j, i)], rv[j], s);
         rv[i] = s * G[tri(i, i)];
       }
-      // v = D z,  w_{0,1} = d - C v
+      // w_{0,1} = d - C v
       double w0 = d0, w1 = d1;
 #pragma unroll
       for (int j = 0; j < MR; ++j) {
-        const double v = rv[j] * dj[j];
+        const double v = rv[j];
         w[j + 2] = v;
         w0 = fma(-C0[j], v, w0);
         w1 = fma(-C1[j], v, w1);
-        ok = ok && isfinite(v);
+        ok = ok && (fabs(v) < 1.0e300);
       }
       w[0] = w0;
       w[1] = w1;
-      ok = ok && isfinite(w0) && isfinite(w1);
+      ok = ok && (fabs(w0) < 1.0e300) && (fabs(w1) < 1.0e300);
       if (!ok) st = LSSVR_ST_FALLBACK;
     }
 
@@ -207,7 +198,7 @@ __global__ __launch_bounds__(kBlock) void enhance_small_kernel(EnhanceArgs p) {
 #pragma unroll
   for (int i = 0; i < M; ++i) tile[tid * M + i] = w[i];
   __syncthreads();
-  const int64_t base = (int64_t)blockIdx.x * kBlock * M;
+  const int64_t base = (int64_t)block * kBlock * M;
   const int64_t total = p.ne * M;
 #pragma unroll
   for (int i = 0; i < M; ++i) {
@@ -216,45 +207,79 @@ __global__ __launch_bounds__(kBlock) void enhance_small_kernel(EnhanceArgs p) {
   }
 }
 
+template <int M, int RHS, bool VC>
+__global__ __launch_bounds__(kBlock) void enhance_small_kernel(EnhanceArgs p) {
+  __shared__ double tile[kBlock * M];
+  enhance_small_body<M, RHS, VC>(p, blockIdx.x, tile);
+}
+
+// One launch for a whole step of the hot path on one mesh: blocks [0, eblocks) run the
+// per-element enhancement, the remaining blocks the element-local P1 assembly (one thread
+// per node).  The two halves share nothing but the node array, so fusing them only removes
+// a launch boundary and lets the short assembly run in the shadow of the enhancement.
+template <int M>
+__global__ __launch_bounds__(kBlock) void step_small_kernel(EnhanceArgs p, P1Args a, QuadRule q,
+                                                             unsigned eblocks) {
+  __shared__ double tile[kBlock * M];
+  if (blockIdx.x < eblocks) {
+    enhance_small_body<M, LSSVR_RHS_SIN, false>(p, blockIdx.x, tile);
+  } else {
+    const int64_t i = (int64_t)(blockIdx.x - eblocks) * kBlock + threadIdx.x;
+    if (i <= a.ne) p1_node<true>(a, q, i);
+  }
+}
+
 // ----------------------------------------------------------------------------
 // dispatch
 // ----------------------------------------------------------------------------
 template <int M, int RHS, bool VC>
-static hipError_t launch_small(const EnhanceArgs& a, hipStream_t s) {
+static hipError_t launch_small(const EnhanceArgs& a, hipStream_t s, const LaunchOpts* o) {
   const unsigned blocks = (unsigned)((a.ne + kBlock - 1) / kBlock);
-  hipLaunchKernelGGL((enhance_small_kernel<M, RHS, VC>), dim3(blocks), dim3(kBlock), 0, s, a);
-  return hipGetLastError();
+  return launch(enhance_small_kernel<M, RHS, VC>, dim3(blocks), dim3(kBlock), s, o, a);
 }
 
+template <int M>
+static hipError_t launch_step(const EnhanceArgs& e, const P1Args& a, const QuadRule& q,
+                              hipStream_t s, const LaunchOpts* o) {
+  const unsigned eb = (unsigned)((e.ne + kBlock - 1) / kBlock);
+  const unsigned ab = (unsigned)((a.ne + 1 + kBlock - 1) / kBlock);
+  return launch(step_small_kernel<M>, dim3(eb + ab), dim3(kBlock), s, o, e, a, q, eb);
+}
+
+#define LSSVR_FOR_EACH_SMALL_M(X) \
+  X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14)
+
 template <int RHS, bool VC>
-static hipError_t dispatch_m(const EnhanceArgs& a, hipStream_t s) {
+static hipError_t dispatch_m(const EnhanceArgs& a, hipStream_t s, const LaunchOpts* o) {
   switch (a.M) {
 #define LSSVR_CASE(MM) \
   case MM:             \
-    return launch_small<MM, RHS, VC>(a, s);
-    LSSVR_CASE(2)
-    LSSVR_CASE(3)
-    LSSVR_CASE(4)
-    LSSVR_CASE(5)
-    LSSVR_CASE(6)
-    LSSVR_CASE(7)
-    LSSVR_CASE(8)
-    LSSVR_CASE(9)
-    LSSVR_CASE(10)
-    LSSVR_CASE(11)
-    LSSVR_CASE(12)
-    LSSVR_CASE(13)
-    LSSVR_CASE(14)
+    return launch_small<MM, RHS, VC>(a, s, o);
+    LSSVR_FOR_EACH_SMALL_M(LSSVR_CASE)
 #undef LSSVR_CASE
     default:
       return hipErrorInvalidValue;
   }
 }
 
-hipError_t enhance_small(const EnhanceArgs& a, hipStream_t s) {
-  if (a.a_values) return dispatch_m<LSSVR_RHS_ARRAY, true>(a, s);
-  if (a.rhs_id == LSSVR_RHS_SIN) return dispatch_m<LSSVR_RHS_SIN, false>(a, s);
-  return dispatch_m<LSSVR_RHS_ARRAY, false>(a, s);
+hipError_t enhance_small(const EnhanceArgs& a, hipStream_t s, const LaunchOpts* o) {
+  if (a.a_values) return dispatch_m<LSSVR_RHS_ARRAY, true>(a, s, o);
+  if (a.rhs_id == LSSVR_RHS_SIN) return dispatch_m<LSSVR_RHS_SIN, false>(a, s, o);
+  return dispatch_m<LSSVR_RHS_ARRAY, false>(a, s, o);
+}
+
+hipError_t step_small(const EnhanceArgs& e, const P1Args& a, hipStream_t s, const LaunchOpts* o) {
+  QuadRule q;
+  if (!quad_rule(a.nquad, q)) return hipErrorInvalidValue;
+  switch (e.M) {
+#define LSSVR_CASE(MM) \
+  case MM:             \
+    return launch_step<MM>(e, a, q, s, o);
+    LSSVR_FOR_EACH_SMALL_M(LSSVR_CASE)
+#undef LSSVR_CASE
+    default:
+      return hipErrorInvalidValue;
+  }
 }
 
 }  // namespace lssvr

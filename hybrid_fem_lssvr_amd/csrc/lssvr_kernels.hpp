@@ -1,6 +1,7 @@
 // Internal launch interface between the C-ABI layer (capi.hip) and the kernels.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include "../../include/lssvr_hip.h"
 
@@ -25,11 +26,33 @@ struct EnhanceArgs {
   int32_t* fail_count;
 };
 
-hipError_t enhance_small(const EnhanceArgs& a, hipStream_t s);
-hipError_t enhance_large(const EnhanceArgs& a, hipStream_t s);
-hipError_t enhance_dual(const EnhanceArgs& a, hipStream_t s);
+// Optional per-launch profiling: when both events are set the kernel goes through
+// hipExtLaunchKernelGGL, which stamps them with the dispatch's own begin/end times.
+struct LaunchOpts {
+  hipEvent_t start = nullptr;
+  hipEvent_t stop = nullptr;
+};
+
+template <typename K, typename... Args>
+inline hipError_t launch(K kernel, dim3 grid, dim3 block, hipStream_t s, const LaunchOpts* o,
+                         Args... args) {
+  if (o && o->start && o->stop)
+    hipExtLaunchKernelGGL(kernel, grid, block, 0, s, o->start, o->stop, 0, args...);
+  else
+    hipLaunchKernelGGL(kernel, grid, block, 0, s, args...);
+  return hipGetLastError();
+}
+
+hipError_t enhance_small(const EnhanceArgs& a, hipStream_t s, const LaunchOpts* o = nullptr);
+hipError_t enhance_large(const EnhanceArgs& a, hipStream_t s, const LaunchOpts* o = nullptr);
+hipError_t enhance_dual(const EnhanceArgs& a, hipStream_t s, const LaunchOpts* o = nullptr);
 
 hipError_t colloc_points(const double* x, int64_t ne, int n, double* xc, hipStream_t s);
+
+struct QuadRule {
+  double xi[5];
+  double wt[5];
+};
 
 struct P1Args {
   const double* x;
@@ -46,6 +69,9 @@ struct P1Args {
   double* floc;
 };
 hipError_t p1_assemble(const P1Args& a, hipStream_t s);
+// assembly + enhancement of the same mesh in ONE launch (lane-per-element path, in-kernel rhs)
+hipError_t step_small(const EnhanceArgs& e, const P1Args& a, hipStream_t s,
+                      const LaunchOpts* o = nullptr);
 hipError_t quad_points(const double* x, int64_t ne, int nquad, double* xq, hipStream_t s);
 
 int64_t tridiag_work_bytes(int64_t ne);

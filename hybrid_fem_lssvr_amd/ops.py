@@ -96,6 +96,67 @@ def enhance(x, u, M, gamma, n_colloc=12, *, rhs=(POISSON_AMP, POISSON_OMEGA), rh
     return out, status
 
 
+def enhance_profiled(x, u, M, gamma, n_colloc=12, *, rhs=(POISSON_AMP, POISSON_OMEGA),
+                     elem_offset=0, ne_global=None, global_domain, bc=(0.0, 0.0),
+                     solver=SOLVER_PRIMAL, out=None, status=None, stream=None):
+    """Same launch as :func:`enhance` but BLOCKING and stamped with the dispatch's own
+    begin/end timestamps; returns the kernel duration in seconds (roofline measurement)."""
+    import ctypes
+    lib = _capi.load()
+    _dev(x, "x")
+    _dev(u, "u")
+    ne = x.numel() - 1
+    if ne_global is None:
+        ne_global = elem_offset + ne
+    if out is None:
+        out = torch.empty((ne, M), dtype=torch.float64, device=x.device)
+    ms = ctypes.c_float(0.0)
+    rc = lib.lssvr_enhance_profiled(_ptr(x), _ptr(u), ne, int(elem_offset), int(ne_global),
+                                    float(global_domain[0]), float(global_domain[1]),
+                                    float(bc[0]), float(bc[1]), int(M), int(n_colloc), float(gamma),
+                                    RHS_SIN, _capi.rhs_params(*rhs), None, int(solver),
+                                    _ptr(out), _ptr(status), _stream(stream), ctypes.byref(ms))
+    _capi.check(rc, "lssvr_enhance_profiled")
+    return ms.value * 1e-3
+
+
+class StepPlan:
+    """One step of the hot path (element-local P1 assembly + per-element enhancement of
+    the same resident mesh shard) bound once, launched many times: the argument tuple of
+    ``lssvr_step`` is built at construction so that a launch is a single ctypes call."""
+
+    def __init__(self, x, u, M, gamma, n_colloc=12, *, rhs=(POISSON_AMP, POISSON_OMEGA), nquad=2,
+                 elem_offset=0, ne_global=None, global_domain, bc=(0.0, 0.0), bands=None,
+                 out=None, status=None, fail_count=None):
+        self.lib = _capi.load()
+        _dev(x, "x")
+        _dev(u, "u")
+        ne = x.numel() - 1
+        dev = x.device
+        if ne_global is None:
+            ne_global = elem_offset + ne
+        self.bands = bands or {
+            "diag": torch.empty(ne + 1, dtype=torch.float64, device=dev),
+            "off": torch.empty(ne, dtype=torch.float64, device=dev),
+            "load": torch.empty(ne + 1, dtype=torch.float64, device=dev),
+        }
+        self.W = out if out is not None else torch.empty((ne, M), dtype=torch.float64, device=dev)
+        self.status = status if status is not None else torch.empty(ne, dtype=torch.int32, device=dev)
+        self.fail_count = fail_count
+        self._keep = (x, u, _capi.rhs_params(*rhs))
+        self._args = (_ptr(x), _ptr(u), ne, int(elem_offset), int(ne_global),
+                      float(global_domain[0]), float(global_domain[1]), float(bc[0]), float(bc[1]),
+                      int(M), int(n_colloc), float(gamma), self._keep[2], int(nquad),
+                      _ptr(self.bands["diag"]), _ptr(self.bands["off"]), _ptr(self.bands["load"]),
+                      _ptr(self.W), _ptr(self.status), _ptr(fail_count))
+
+    def launch(self, stream=None):
+        rc = self.lib.lssvr_step(*self._args, _stream(stream))
+        if rc < 0:
+            _capi.check(rc, "lssvr_step")
+        return self.W, self.status
+
+
 def enhance_varcoef(x, u, M, gamma, n_colloc, a_values, da_values, rhs_values, *, elem_offset=0,
                     ne_global=None, global_domain=None, bc=(0.0, 0.0), out=None, status=None,
                     fail_count=None, stream=None):

@@ -47,8 +47,8 @@ extern "C" {
 
 /* per-element solver */
 #define LSSVR_SOLVER_PRIMAL 0 /* BC-eliminated primal normal equations, (M-2) SPD,
-                                 Jacobi-scaled Cholesky (default; <=1e-15 of the exact
-                                 minimiser on every BASELINE config)              */
+                                 Cholesky (default; <=1e-15 of the exact minimiser on
+                                 every BASELINE config)                            */
 #define LSSVR_SOLVER_DUAL   1 /* north_star's dual Gram form, (n+2) system, equilibrated
                                  LU with partial pivoting (accuracy-gated) */
 #define LSSVR_SOLVER_PRIMAL_WAVE 2 /* same algorithm as PRIMAL, forced onto the
@@ -101,6 +101,33 @@ int lssvr_enhance(const double* x, const double* u, int64_t ne,
                   int rhs_id, const double* rhs_params_host, const double* rhs_values,
                   int solver_id,
                   double* W, int32_t* status, int32_t* fail_count, void* stream);
+
+/*
+ * lssvr_enhance_profiled -- the same launch as lssvr_enhance, stamped with the
+ * dispatch's own begin/end timestamps (hipExtLaunchKernelGGL).  BLOCKING: waits for
+ * the kernel and returns its duration in *kernel_ms_host.  Measurement aid for
+ * bench.py's roofline; not for production pipelines.
+ */
+int lssvr_enhance_profiled(const double* x, const double* u, int64_t ne,
+                           int64_t elem_offset, int64_t ne_global,
+                           double gxmin, double gxmax, double bc_left, double bc_right,
+                           int M, int n_colloc, double gamma,
+                           int rhs_id, const double* rhs_params_host, const double* rhs_values,
+                           int solver_id,
+                           double* W, int32_t* status, void* stream, float* kernel_ms_host);
+
+/*
+ * lssvr_step -- one whole step of the hot path on one mesh shard in ONE launch:
+ * lssvr_p1_assemble (in-kernel rhs, nquad-point Gauss) + lssvr_enhance (primal
+ * solver, in-kernel rhs).  For M <= 14 the two run as disjoint block ranges of a single
+ * grid; arguments as in the two separate calls.
+ */
+int lssvr_step(const double* x, const double* u, int64_t ne,
+               int64_t elem_offset, int64_t ne_global,
+               double gxmin, double gxmax, double bc_left, double bc_right,
+               int M, int n_colloc, double gamma, const double* rhs_params_host, int nquad,
+               double* diag, double* off, double* load,
+               double* W, int32_t* status, int32_t* fail_count, void* stream);
 
 /*
  * lssvr_enhance_varcoef -- BASELINE config 5, -(a u')' = f (no reference

@@ -1,0 +1,100 @@
+"""CPU: the C-ABI library loads without a GPU and exports every symbol that
+include/lssvr_hip.h declares; argument errors are reported before any HIP call."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "lssvr_hip.h")
+
+
+def _declared():
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(lssvr_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_symbols_exported_and_bound():
+    from hybrid_fem_lssvr_amd import _capi
+    lib = _capi.load()
+    names = _declared()
+    assert "lssvr_enhance" in names and "lssvr_eval" in names and len(names) >= 11
+    for nm in names:
+        assert hasattr(lib, nm), f"{nm} declared in the header but not exported"
+        assert nm in _capi.SIGNATURES, f"{nm} has no ctypes signature"
+    assert sorted(_capi.SIGNATURES) == names
+    assert lib.lssvr_version() == _capi.ABI_VERSION
+    hdr_ver = int(re.search(r"#define LSSVR_ABI_VERSION (\d+)", open(HEADER).read()).group(1))
+    assert hdr_ver == _capi.ABI_VERSION
+
+
+def test_header_constants_match_binding():
+    from hybrid_fem_lssvr_amd import _capi
+    txt = open(HEADER).read()
+    for c_name, py_val in (("LSSVR_RHS_ARRAY", _capi.RHS_ARRAY), ("LSSVR_RHS_SIN", _capi.RHS_SIN),
+                           ("LSSVR_SOLVER_PRIMAL", _capi.SOLVER_PRIMAL),
+                           ("LSSVR_SOLVER_DUAL", _capi.SOLVER_DUAL),
+                           ("LSSVR_SOLVER_PRIMAL_WAVE", _capi.SOLVER_PRIMAL_WAVE),
+                           ("LSSVR_ST_OK", _capi.ST_OK), ("LSSVR_ST_FALLBACK", _capi.ST_FALLBACK)):
+        m = re.search(r"#define %s\s+(\d+)" % c_name, txt)
+        assert m and int(m.group(1)) == py_val, c_name
+
+
+def test_argument_errors_without_gpu():
+    """Validation happens on the host, before any launch: safe to call on a CPU-only box."""
+    from hybrid_fem_lssvr_amd import _capi
+    lib = _capi.load()
+    p = _capi.rhs_params(1.0, 1.0)
+    fake = ctypes.c_void_p(4096)
+    rc = lib.lssvr_enhance(fake, fake, -1, 0, 0, 0.0, 1.0, 0.0, 0.0, 9, 16, 1e4, 1, p, None, 0,
+                           fake, None, None, None)
+    assert rc == -2 and b"ne" in lib.lssvr_last_error()
+    rc = lib.lssvr_enhance(fake, fake, 10, 0, 10, 0.0, 1.0, 0.0, 0.0, 99, 16, 1e4, 1, p, None, 0,
+                           fake, None, None, None)
+    assert rc == -3 and b"M = 99" in lib.lssvr_last_error()
+    rc = lib.lssvr_enhance(fake, fake, 10, 0, 10, 0.0, 1.0, 0.0, 0.0, 9, 16, 1e4, 7, p, None, 0,
+                           fake, None, None, None)
+    assert rc == -4
+    rc = lib.lssvr_enhance(fake, fake, 10, 0, 10, 0.0, 1.0, 0.0, 0.0, 9, 16, 1e4, 0, None, None, 0,
+                           fake, None, None, None)
+    assert rc == -4 and b"rhs_values" in lib.lssvr_last_error()
+    rc = lib.lssvr_enhance(None, fake, 10, 0, 10, 0.0, 1.0, 0.0, 0.0, 9, 16, 1e4, 1, p, None, 0,
+                           fake, None, None, None)
+    assert rc == -1
+    rc = lib.lssvr_enhance(fake, fake, 10, 5, 12, 0.0, 1.0, 0.0, 0.0, 9, 16, 1e4, 1, p, None, 0,
+                           fake, None, None, None)
+    assert rc == -2 and b"shard" in lib.lssvr_last_error()
+    rc = lib.lssvr_enhance(fake, fake, 10, 0, 10, 0.0, 1.0, 0.0, 0.0, 9, 16, 1e4, 1, p, None, 9,
+                           fake, None, None, None)
+    assert rc == -5
+    # empty shard: success without touching the device
+    rc = lib.lssvr_enhance(None, None, 0, 0, 0, 0.0, 1.0, 0.0, 0.0, 9, 16, 1e4, 1, p, None, 0,
+                           None, None, None, None)
+    assert rc == 0
+    assert lib.lssvr_p1_assemble(fake, 10, 9, 1, p, None, None, fake, fake, fake, None, None, None) == -7
+    assert lib.lssvr_eval(fake, fake, 0, 9, fake, 1, fake, None, None) == -2
+    assert lib.lssvr_tridiag_work_bytes(100000) > 8 * 100000
+    with pytest.raises(_capi.LssvrHipError):
+        _capi.check(-3, "demo")
+
+
+def test_ops_reject_host_tensors():
+    import torch
+    from hybrid_fem_lssvr_amd import ops
+    x = torch.linspace(0, 1, 5, dtype=torch.float64)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.enhance(x, x, 5, 1e4, 12, global_domain=(0.0, 1.0))
+    with pytest.raises(TypeError):
+        ops.enhance([0.0, 1.0], x, 5, 1e4, 12)
+
+
+def test_product_does_not_import_oracle():
+    """The oracle is test infrastructure: nothing under the package may import it."""
+    pkg = os.path.join(ROOT, "hybrid_fem_lssvr_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f

@@ -1,0 +1,80 @@
+"""CPU, world_size 2, gloo: the N > 1 path -- shard plan, boundary flags through
+elem_offset / ne_global, and the chunked all-gather that stitches W.  The per-shard
+compute is the oracle here (no GPU in this container); the stitching code is the
+product's (hybrid_fem_lssvr_amd.distributed), backend-agnostic by construction."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import lssvr_oracle as orc
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, ne, M, n, chunks, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from hybrid_fem_lssvr_amd.distributed import ShardPlan, allgather_rows
+        nodes = np.linspace(-1, 1, ne + 1)
+        values = np.cos(2 * nodes)                       # non-zero at the ends on purpose
+        plan = ShardPlan(ne, world)
+        s0, s1 = plan.bounds(rank)
+        sl = plan.node_slice(rank)
+
+        def compute(lo, hi, dst):
+            # stand-in for ops.enhance(x[lo:hi+1], u[lo:hi+1], elem_offset=s0+lo, ne_global=ne)
+            W = np.zeros((hi - lo, M))
+            xs, us = nodes[sl][lo:hi + 1], values[sl][lo:hi + 1]
+            for k in range(hi - lo):
+                gl, gr = orc.boundary_values(s0 + lo + k, ne, xs[k], xs[k + 1], us[k], us[k + 1], (-1.0, 1.0))
+                W[k] = orc.solve_bc_eliminated(orc.element_system(xs[k], xs[k + 1], gl, gr, M, 1e4, n))
+            dst.copy_(torch.from_numpy(W))
+
+        local = torch.zeros((plan.max_size, M), dtype=torch.float64)
+        Wg = allgather_rows(local, plan, rank, chunks=chunks, compute_chunk=compute)
+        q.put((rank, Wg.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("ne,chunks", [(11, 1), (12, 3), (7, 4)])
+def test_two_rank_gloo_stitch(ne, chunks):
+    M, n, world = 6, 8, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ne, M, n, chunks, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    nodes = np.linspace(-1, 1, ne + 1)
+    Wref, _ = orc.enhance_all(nodes, np.cos(2 * nodes), M, 1e4, n, global_domain=(-1.0, 1.0))
+    for r in range(world):
+        assert np.array_equal(got[r], Wref), f"rank {r}"       # every rank holds the global W
+    # only the two global-boundary elements saw the Dirichlet value (Dual.py:150-151)
+    assert abs(orc.clenshaw(-1.0, Wref[0])) < 1e-13
+    assert abs(orc.clenshaw(1.0, Wref[0]) - np.cos(2 * nodes[1])) < 1e-12
+
+
+def test_single_rank_allgather_is_identity():
+    from hybrid_fem_lssvr_amd.distributed import ShardPlan, allgather_rows
+    plan = ShardPlan(9, 1)
+    local = torch.arange(27, dtype=torch.float64).reshape(9, 3)
+    out = allgather_rows(local, plan, 0, chunks=2)
+    assert torch.equal(out, local)

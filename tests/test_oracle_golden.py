@@ -1,0 +1,145 @@
+"""CPU: the oracle pinned against the golden vectors generated from the reference
+(tests/golden/*.npz, made by oracle/gen_golden.py in the build container).
+
+The reference ships no tests or fixtures of its own; these vectors
+hold, per element, the reference's SLSQP output and the 60-digit minimiser of the same QP."""
+import numpy as np
+import pytest
+
+from oracle import lssvr_oracle as orc
+from oracle import closed_form_mp as cf
+
+CASES = [
+    ("G1_c1_ne8_M5_n5", 3e-10),
+    ("G2_default_ne24_M8_n12", 1e-10),
+    ("G3_ne24_M9_n16", 1e-10),
+    ("G4_ne4096_M9_n16", 1e-10),
+    ("G5_ne24_M33_n64", 1e-10),
+    ("G6a_wide_ne100008_M9_n16", 1e-10),
+    ("G6b_wide_ne10000008_M9_n16", 2e-10),
+    ("G8_classdefaults_ne4_M12_n12", 3e-10),
+]
+
+
+def _systems(g):
+    lo, hi, ne = float(g["lo"]), float(g["hi"]), int(g["ne"])
+    M, n, gamma = int(g["M"]), int(g["n"]), float(g["gamma"])
+    for k, e in enumerate(g["elements"]):
+        a, b = g["nodes_sel"][k]
+        ul, ur = g["values_sel"][k]
+        gl, gr = orc.boundary_values(int(e), ne, a, b, ul, ur, (lo, hi))
+        yield k, orc.element_system(a, b, gl, gr, M, gamma, n)
+
+
+@pytest.mark.parametrize("name,tol_ref", CASES)
+def test_closed_forms_vs_golden(golden, name, tol_ref):
+    g = golden(name)
+    nodes = np.linspace(float(g["lo"]), float(g["hi"]), int(g["ne"]) + 1)
+    assert np.array_equal(nodes[g["elements"]], g["nodes_sel"][:, 0])        # node indices exact
+    assert np.array_equal(nodes[g["elements"] + 1], g["nodes_sel"][:, 1])
+    for k, s in _systems(g):
+        w_bce = orc.solve_bc_eliminated(s)        # the algorithm of the HIP kernels
+        w_kkt = orc.solve_primal_kkt(s)
+        assert orc.rel_l2_coef(w_bce, g["coef_truth"][k]) <= 1e-13
+        assert orc.rel_l2_coef(w_kkt, g["coef_truth"][k]) <= 1e-13
+        assert orc.rel_l2_coef(w_bce, g["coef_ref"][k]) <= tol_ref
+    # the reference itself sits this far from the exact minimiser
+    assert orc.rel_l2_coef(g["coef_ref"], g["coef_truth"]).max() <= tol_ref
+
+
+@pytest.mark.skipif(not cf.HAVE_MP, reason="mpmath missing")
+@pytest.mark.parametrize("name", ["G1_c1_ne8_M5_n5", "G3_ne24_M9_n16", "G6b_wide_ne10000008_M9_n16"])
+def test_truth_regenerates(golden, name):
+    g = golden(name)
+    for k, s in list(_systems(g))[:3]:
+        assert orc.rel_l2_coef(cf.solve_truth(s), g["coef_truth"][k]) <= 1e-15
+
+
+def test_dual_gram_form_accuracy(golden):
+    """north_star's (n+2) Gram form: fine at h = 1/12, visibly worse on config 1
+     -- which is why it is not the default solver."""
+    g = golden("G3_ne24_M9_n16")
+    errs = [orc.rel_l2_coef(orc.solve_dual_gram(s), g["coef_truth"][k]) for k, s in _systems(g)]
+    assert max(errs) <= 1e-12
+    g1 = golden("G1_c1_ne8_M5_n5")
+    errs1 = [orc.rel_l2_coef(orc.solve_dual_gram(s), g1["coef_truth"][k]) for k, s in _systems(g1)]
+    assert max(errs1) <= 1e-8
+
+
+def test_slsqp_restatement_reproduces_reference(golden):
+    """The CPU baseline (per-element SLSQP loop) against the reference's own output."""
+    g = golden("G3_ne24_M9_n16")
+    nodes = np.linspace(-1, 1, 25)
+    vals = np.concatenate([g["values_sel"][:, 0], g["values_sel"][-1:, 1]])
+    C, ok = orc.slsqp_loop(nodes, vals, 9, 1e4, 16, elements=[0, 11, 23])
+    assert ok.all()
+    assert orc.rel_l2_coef(C, g["coef_ref"][[0, 11, 23]]).max() <= 1e-10
+    assert orc.rel_l2_coef(C, g["coef_truth"][[0, 11, 23]]).max() <= 1e-10
+
+
+def test_numpy_arithmetic_restatements():
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        a = rng.uniform(-1e6, 1e6)
+        b = a + rng.uniform(1e-7, 10)
+        n = int(rng.integers(2, 70))
+        assert np.array_equal(orc.np_linspace(a, b, n), np.linspace(a, b, n))
+    from numpy.polynomial import polyutils as pu
+    from numpy.polynomial.legendre import Legendre, legval
+    off, scl = orc.mapparms(0.3, 0.7)
+    assert (off, scl) == tuple(pu.mapparms([0.3, 0.7], [-1, 1]))
+    c = rng.standard_normal(9)
+    t = rng.uniform(-1, 1, 33)
+    assert np.array_equal(orc.clenshaw(t, c), legval(t, c))
+    # PDE rows through legder + legval == -scl^2 L'' to rounding, both recurrences
+    A = orc.legendre_rows_reference(0.3, 0.7, 9, np.linspace(0.3, 0.7, 16))
+    s = orc.element_system(0.3, 0.7, 0.0, 0.0, 9, 1e4, 16)
+    assert np.max(np.abs(A - s.scl ** 2 * s.Ahat)) <= 1e-13 * np.max(np.abs(A))
+    assert np.max(np.abs(orc.gegenbauer_d2(s.t, 9) + s.Ahat)) <= 1e-13 * np.max(np.abs(s.Ahat))
+    L, D1, D2 = orc.legendre_tables(s.t, 9)
+    assert np.max(np.abs(orc.gegenbauer_d1(s.t, 9) - D1)) <= 1e-13 * np.max(np.abs(D1))
+    u = Legendre(c, [0.3, 0.7])
+    assert np.allclose(-u.deriv(2)(s.x), s.scl ** 2 * (s.Ahat @ c), rtol=1e-12)
+
+
+def test_evaluate_solution_vs_reference(golden):
+    g = golden("G7_eval_default")
+    u, elem = orc.evaluate_solution(g["nodes"], g["W"], g["xq"])
+    assert np.array_equal(elem, g["elem"])
+    assert np.array_equal(u, g["u_ref"])
+    uv, ev = orc.evaluate_solution_vec(g["nodes"], g["W"], g["xq"])
+    assert np.array_equal(ev, g["elem"]) and np.array_equal(uv, g["u_ref"])
+    assert np.array_equal(orc.locate_elements_scan(g["nodes"], g["xq"]), g["elem"])
+
+
+def test_p1_fem_analytic_pins():
+    """scikit-fem is absent: the P1 step is pinned by the analytic tridiagonal system and by
+    the manufactured solution."""
+    nodes = np.linspace(-1, 1, 25)
+    kd, fl, fr = orc.p1_assemble_local(nodes)
+    assert np.allclose(kd, 12.0)
+    diag, off, load = orc.p1_scatter(kd, fl, fr)
+    assert np.allclose(diag[1:-1], 24.0) and np.allclose(off, -12.0)
+    u = orc.thomas_dirichlet(diag, off, load)
+    assert abs(np.max(np.abs(u - np.sin(np.pi * nodes))) - 3.274e-6) < 2e-9
+    assert np.max(np.abs(orc.banded_dirichlet(diag, off, load) - u)) < 1e-14
+    n8 = np.linspace(-1, 1, 9)
+    u8 = orc.fem_p1_solve(n8)
+    assert abs(np.max(np.abs(u8 - np.sin(np.pi * n8))) - 2.731e-4) < 2e-7
+    # hybrid accuracy of SURVEY.md Appendix B.1 (reference demo configuration)
+    W, st = orc.enhance_all(nodes, u, 8, 1e4, 12)
+    xq = np.linspace(-1, 1, 201)
+    uq, _ = orc.evaluate_solution(nodes, W, xq)
+    ex = orc.true_solution(xq)
+    assert abs(np.linalg.norm(uq - ex) / np.linalg.norm(ex) - 3.255e-6) < 5e-9
+    assert np.all(st == 0)
+
+
+def test_batched_oracle_equals_loop():
+    rng = np.random.default_rng(5)
+    nodes = np.cumsum(np.concatenate([[0.0], rng.uniform(0.01, 0.2, 40)]))
+    vals = rng.standard_normal(41)
+    for M, n in ((5, 5), (9, 16), (12, 12)):
+        Wl, _ = orc.enhance_all(nodes, vals, M, 1e4, n, solver="primal")
+        Wv = orc.enhance_all_vec(nodes, vals, M, 1e4, n)
+        assert orc.rel_l2_coef(Wv, Wl).max() <= 1e-13
