@@ -59,6 +59,7 @@ SIGNATURES = {
                                                _c_dp, _c_dp, _c_dp]),
     "lssvr_eval": (_c_int, [_c_dp, _c_dp, _c_i64, _c_int, _c_dp, _c_i64, _c_dp, _c_dp, _c_dp]),
     "lssvr_fp64_probe": (_c_int, [_c_dp, _c_int, _c_int, _c_int, _c_dp]),
+    "lssvr_stream_probe": (_c_int, [_c_dp, _c_dp, _c_i64, _c_dp]),
 }
 
 _lib = None

@@ -274,6 +274,13 @@ int lssvr_eval(const double* x, const double* W, int64_t ne, int M, const double
                       "eval_points");
 }
 
+int lssvr_stream_probe(const double* src, double* dst, int64_t n, void* stream) {
+  if (!src || !dst) return fail(LSSVR_ERR_NULL, "src and dst must be non-NULL");
+  if (n < 1) return fail(LSSVR_ERR_SIZE, "n must be >= 1");
+  return check_launch(lssvr::stream_probe(src, dst, n, reinterpret_cast<hipStream_t>(stream)),
+                      "stream_probe");
+}
+
 int lssvr_fp64_probe(double* out, int blocks, int iters, int use_mfma, void* stream) {
   if (!out) return fail(LSSVR_ERR_NULL, "out must be non-NULL");
   if (blocks < 1 || iters < 1) return fail(LSSVR_ERR_SIZE, "blocks and iters must be >= 1");

@@ -185,6 +185,23 @@ __global__ __launch_bounds__(kBlock) void fp64_mfma_probe_kernel(double* out, in
   out[tid] = (c0[0] + c1[1]) + (c2[2] + c3[3]);
 }
 
+// 8-byte-per-lane streaming copy with a known byte count: calibrates rocprofv3's
+// FETCH_SIZE / WRITE_SIZE for the access width the enhancement kernels use.
+__global__ __launch_bounds__(kBlock) void stream_copy_probe_kernel(const double* __restrict__ src,
+                                                                    double* __restrict__ dst,
+                                                                    int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * kBlock)
+    dst[i] = src[i] + 1.0;
+}
+
+hipError_t stream_probe(const double* src, double* dst, int64_t n, hipStream_t s) {
+  const int64_t b = (n + kBlock - 1) / kBlock;
+  hipLaunchKernelGGL(stream_copy_probe_kernel, dim3((unsigned)(b < 16384 ? b : 16384)),
+                     dim3(kBlock), 0, s, src, dst, n);
+  return hipGetLastError();
+}
+
 hipError_t fp64_probe(double* out, int blocks, int iters, int use_mfma, hipStream_t s) {
   if (use_mfma)
     hipLaunchKernelGGL(fp64_mfma_probe_kernel, dim3(blocks), dim3(kBlock), 0, s, out, iters);

@@ -83,5 +83,6 @@ hipError_t eval_points(const double* x, const double* W, int64_t ne, int M, cons
                        int64_t P, double* uq, int64_t* elem, hipStream_t s);
 
 hipError_t fp64_probe(double* out, int blocks, int iters, int use_mfma, hipStream_t s);
+hipError_t stream_probe(const double* src, double* dst, int64_t n, hipStream_t s);
 
 }  // namespace lssvr

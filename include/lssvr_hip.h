@@ -205,6 +205,13 @@ int lssvr_eval(const double* x, const double* W, int64_t ne, int M,
  */
 int lssvr_fp64_probe(double* out, int blocks, int iters, int use_mfma, void* stream);
 
+/*
+ * lssvr_stream_probe -- dst[i] = src[i] + 1 over n doubles with 8-byte-per-lane
+ * accesses (8n bytes read, 8n written): a known byte count in the enhancement
+ * kernels' access width, used to calibrate rocprofv3's FETCH_SIZE / WRITE_SIZE.
+ */
+int lssvr_stream_probe(const double* src, double* dst, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
