@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "liblssvr_hip.so")
+# LSSVR_HIP_LIB selects another build of the same ABI (kernel A/B experiments)
+LIB_PATH = os.environ.get("LSSVR_HIP_LIB") or os.path.join(_HERE, "csrc", "liblssvr_hip.so")
 
 ABI_VERSION = 1
 

@@ -13,7 +13,7 @@
 //      w_{0,1} = d - C v;
 //   5. S = G + eps (I + C^T C), Cholesky, two triangular solves;
 //   6. status / linear-interpolant fallback (Dual.py:164-169).
-// The 256 x M coefficient tile of a workgroup is transposed through LDS so that
+// Each wave transposes its 64 x M coefficient tile through (wave-private) LDS so that
 // the store to W[ne, M] (row-major, 8*M B per element) is fully coalesced.
 //
 // Why lane-per-element rather than a wave-cooperative factorisation: the system
@@ -194,16 +194,22 @@ __device__ __forceinline__ void enhance_small_body(const EnhanceArgs& p, const u
     if (p.status) p.status[e] = st;
   }
 
-  // --- coalesced store of the workgroup's 256 x M tile -------------------------
+  // --- coalesced store: each wave transposes its own 64 x M tile through LDS --------
+  // (wave-private, so no workgroup barrier: a wave that finishes early stores early;
+  // LDS operations of one wave execute in order)
+  const int lane = tid & 63;
+  double* const wt = tile + (tid >> 6) * (64 * M);
 #pragma unroll
-  for (int i = 0; i < M; ++i) tile[tid * M + i] = w[i];
-  __syncthreads();
-  const int64_t base = (int64_t)block * kBlock * M;
+  for (int i = 0; i < M; ++i) wt[lane * M + i] = w[i];
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int64_t base = ((int64_t)block * kBlock + (tid & ~63)) * M;
   const int64_t total = p.ne * M;
 #pragma unroll
   for (int i = 0; i < M; ++i) {
-    const int64_t idx = base + (int64_t)i * kBlock + tid;
-    if (idx < total) p.W[idx] = tile[i * kBlock + tid];
+    const int64_t idx = base + (int64_t)i * 64 + lane;
+    // write-once output: non-temporal stores leave less for the end-of-kernel L2 write-back
+    if (idx < total) __builtin_nontemporal_store(wt[i * 64 + lane], &p.W[idx]);
   }
 }
 
