@@ -61,7 +61,14 @@ namespace {
 // shared tail of lssvr_enhance / lssvr_enhance_profiled
 int enhance_dispatch(const lssvr::EnhanceArgs& a, int solver_id, hipStream_t s,
                      const lssvr::LaunchOpts* o) {
-  if (solver_id == LSSVR_SOLVER_DUAL) return check_launch(lssvr::enhance_dual(a, s, o), "enhance_dual");
+  // Fewer collocation points than bubble coefficients: the primal normal equations are rank
+  // deficient (float64 returns O(1) errors there), the dual Gram system is well conditioned.
+  if (solver_id != LSSVR_SOLVER_DUAL && a.n < a.M - 2 && !a.a_values) solver_id = LSSVR_SOLVER_DUAL;
+  if (solver_id == LSSVR_SOLVER_DUAL) {
+    if (a.n > 29) return fail(LSSVR_ERR_SIZE, "dual solver: n_colloc = %d > 29", a.n);
+    if (a.M > 32) return fail(LSSVR_ERR_DEGREE, "dual solver: M = %d > 32", a.M);
+    return check_launch(lssvr::enhance_dual(a, s, o), "enhance_dual");
+  }
   if (a.M <= lssvr::kSmallMaxM && solver_id == LSSVR_SOLVER_PRIMAL)
     return check_launch(lssvr::enhance_small(a, s, o), "enhance_small");
   return check_launch(lssvr::enhance_large(a, s, o), "enhance_large");

@@ -28,62 +28,11 @@
 // one wave's MFMA phase overlaps its neighbours' VALU phases.
 #include "lssvr_device.hpp"
 #include "lssvr_kernels.hpp"
+#include "lssvr_wave.hpp"
 
 namespace lssvr {
 
-namespace {
-
-constexpr int kLP = 32;                 // padded size of the augmented system
-constexpr int kCH = 32;                 // collocation points per chunk
-constexpr int kSV = 34;                 // Vt column stride (doubles)
-constexpr int kSG = 33;                 // G row stride (doubles)
-constexpr int kSL = 34;                 // L row stride (even: 16-B aligned row pairs)
-constexpr int kVDoubles = kLP * kSV;    // 1088 = 32*34 >= 32*33 (G and L alias Vt)
-constexpr int kHalfDoubles = kVDoubles + 3 * kLP;   // Vt | E0 | E1 | Z
-constexpr int kWaveDoubles = 2 * kHalfDoubles;
-constexpr int kWavesPerBlock = 4;
-
-typedef double double4_t __attribute__((ext_vector_type(4)));
-typedef double double2_t __attribute__((ext_vector_type(2)));
-
-// recurrence coefficients, index m: q_m = al2[m] t q_{m-1} - be2[m] q_{m-2} (L'' family),
-// r_m = al1[m] t r_{m-1} - be1[m] r_{m-2} (L' family)
-struct RecTables {
-  double al2[kLP + 2], be2[kLP + 2], al1[kLP + 2], be1[kLP + 2];
-};
-
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
-
-__device__ __forceinline__ double readlane_f64(double v, int srclane) {
-  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-  const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, srclane);
-  const unsigned hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), srclane);
-  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-}
-
-// sum over the 32 lanes of a half
-__device__ __forceinline__ double half_sum(double v) {
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
-
-// L_p(t) for t = +-1 -/+ 2s, |s| tiny:  L_p(1-2s) = sum_k (-1)^k C(p,k) C(p+k,k) s^k
-__device__ __forceinline__ double legendre_near_one(int p, double s) {
-  constexpr double kInvSq[6] = {1.0, 1.0 / 4.0, 1.0 / 9.0, 1.0 / 16.0, 1.0 / 25.0, 1.0 / 36.0};
-  double term = 1.0, sum = 1.0;
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    term *= (-s * kInvSq[k]) * (double)((p - k) * (p + k + 1));
-    sum += term;
-  }
-  return sum;
-}
-
-}  // namespace
+using namespace wave;
 
 template <int RHS, bool VC>
 __global__ __launch_bounds__(kWavesPerBlock * 64, 2) void enhance_large_kernel(EnhanceArgs p,
@@ -102,7 +51,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 2) void enhance_large_kernel(E
   double* const E1 = E0 + kLP;                     // C1_j, d1, 0
   double* const Z = E1 + kLP;                      // back-substitution broadcast vector
   const int M = p.M, MR = M - 2, n = p.n;
-  const int ntile = (MR + 1 > 16) ? 2 : 1;
+  constexpr int ntile = 2;            // the rhs column sits at index 31: always both tile rows
+  const bool need11 = MR > 16;        // tile (1,1) holds nothing but padding otherwise
   const int64_t npair = (p.ne + 1) >> 1;
 
   for (int64_t pr = (int64_t)blockIdx.x * kWavesPerBlock + wave; pr < npair;
@@ -158,10 +108,10 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 2) void enhance_large_kernel(E
     {
       double e0 = (tbb * La2 - ta * Lb2) * idet;
       double e1 = (Lb2 - La2) * idet;
-      if (c == MR) {
+      if (c == kRhsRow) {
         e0 = d0;
         e1 = d1;
-      } else if (c > MR) {
+      } else if (c >= MR) {
         e0 = 0.0;
         e1 = 0.0;
       }
@@ -217,8 +167,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 2) void enhance_large_kernel(E
             r1 = rn;
           }
         }
-        Vt[MR * kSV + c] = phi;
-        for (int j = MR + 1; j < kLP; ++j) Vt[j * kSV + c] = 0.0;
+        for (int j = MR; j < kRhsRow; ++j) Vt[j * kSV + c] = 0.0;
+        Vt[kRhsRow * kSV + c] = phi;        // rhs always rides in the last column
       }
       wave_lds_sync();
       const int ar = (lane & 15) * kSV + (lane >> 4);
@@ -233,8 +183,10 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 2) void enhance_large_kernel(E
           const double b1 = VtB[ar + 16 * kSV + 4 * s];
           accA10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a0, accA10, 0, 0, 0);
           accB10 = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, b0, accB10, 0, 0, 0);
-          accA11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, accA11, 0, 0, 0);
-          accB11 = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, b1, accB11, 0, 0, 0);
+          if (need11) {
+            accA11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, accA11, 0, 0, 0);
+            accB11 = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, b1, accB11, 0, 0, 0);
+          }
         }
       }
     }
@@ -271,63 +223,15 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 2) void enhance_large_kernel(E
         col[i] = fma(eps, add, Gb[i * kSG + c]);
       }
     }
-    wave_lds_sync();    // G is dead from here on; the factor L (stride 34) reuses the region
+    wave_lds_sync();    // G is dead from here on; the factor (stride 34) reuses the region
 
-    // ---- right-looking Cholesky, rhs carried as row/column MR --------------------------------
-    // A non-positive or non-finite pivot turns into NaN through rsqrt and reaches every
-    // later entry of the solution: one finiteness test at the end suffices.  Dead columns
-    // (c < j) write zeros so that the stored factor has an exactly zero upper triangle.
-    // (cc is an opaque copy of c: otherwise hipcc hoists all 31 lane masks (c < j) out
-    // of the element loop and spills them to VGPR lanes.)
-    int cc = c;
-    asm volatile("" : "+v"(cc));
-#pragma unroll
-    for (int j = 0; j < kLP - 1; ++j) {
-      if (j < MR) {
-        const double pA = readlane_f64(col[j], j);
-        const double pB = readlane_f64(col[j], 32 + j);
-        const double linv = rsqrt_newton(h ? pB : pA);
-        const double lcj = (cc < j) ? 0.0 : col[j] * linv;    // l_cj = a_jc / sqrt(piv)
-        Lm[j * kSL + c] = lcj;
-        wave_lds_sync();
-        if ((j + 1) & 1) col[j + 1] = fma(-Lm[j * kSL + j + 1], lcj, col[j + 1]);
-#pragma unroll
-        for (int i = (j + 2) & ~1; i < kLP; i += 2) {
-          const double2_t l2 = *reinterpret_cast<const double2_t*>(&Lm[j * kSL + i]);
-          col[i] = fma(-l2[0], lcj, col[i]);
-          col[i + 1] = fma(-l2[1], lcj, col[i + 1]);
-        }
-      }
-    }
-    wave_lds_sync();
-
-    // ---- backward substitution L^T z = y,  y_j = L[MR][j] = Lm[j][MR] ------------------------
-    // Lane t owns y_t.  The factor's diagonal is zeroed after 1/l_tt has been taken, the
-    // upper triangle is zero already, so y_t freezes once step t has passed and
-    // z_t = y_t / l_tt stays valid in the lane.
-    double y = Lm[c * kSL + MR];
-    double dinv = rcp_newton(Lm[c * kSL + c]);
-    if (c >= MR) {
-      y = 0.0;
-      dinv = 0.0;
-    }
-    wave_lds_sync();
-    Lm[c * kSL + c] = 0.0;
-#pragma unroll
-    for (int i = kLP - 2; i >= 0; --i) {
-      if (i < MR) {
-        Z[c] = y * dinv;
-        wave_lds_sync();
-        const double zi = Z[i];
-        const double lit = Lm[c * kSL + i];       // L[i][c] (column c of the factor), 0 for i <= c
-        y = fma(-lit, zi, y);
-      }
-    }
-    const double v = (c < MR) ? y * dinv : 0.0;
+    // ---- LDL^T factor + solve of the MR x MR block, rhs carried as row/column 31 ------------
+    bool piv_ok;
+    const double v = ldlt_solve(col, Lm, Z, c, MR, piv_ok);
     const double w0 = d0 - half_sum(E0[c] * v);
     const double w1 = d1 - half_sum(E1[c] * v);
     const double bad = half_sum((fabs(v) < 1.0e300) ? 0.0 : 1.0);
-    const bool ok = (bad == 0.0) && (fabs(w0) < 1e300) && (fabs(w1) < 1e300);
+    const bool ok = piv_ok && (bad == 0.0) && (fabs(w0) < 1e300) && (fabs(w1) < 1e300);
 
     // ---- store: lane c -> W[e][c+2]; lane 0 also writes w0, w1 -----------------------------
     if (live) {
@@ -343,20 +247,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 2) void enhance_large_kernel(E
   }
 }
 
-static RecTables make_tables() {
-  RecTables t{};
-  for (int m = 1; m < kLP + 2; ++m) {
-    t.al2[m] = (double)(2 * m + 3) / (double)m;
-    t.be2[m] = (double)(m + 3) / (double)m;
-    t.al1[m] = (double)(2 * m + 1) / (double)m;
-    t.be1[m] = (double)(m + 1) / (double)m;
-  }
-  return t;
-}
-
 hipError_t enhance_large(const EnhanceArgs& a, hipStream_t s, const LaunchOpts* o) {
   if (a.M - 2 + 1 > kLP) return hipErrorInvalidValue;
-  static const RecTables tables = make_tables();
+  static const RecTables tables = make_rec_tables();
   const int64_t npair = (a.ne + 1) / 2;
   int64_t blocks = (npair + kWavesPerBlock - 1) / kWavesPerBlock;
   const int64_t cap = 256 * 2 * 8;            // 8 rounds of a full chip at 2 blocks per CU
@@ -367,10 +260,6 @@ hipError_t enhance_large(const EnhanceArgs& a, hipStream_t s, const LaunchOpts* 
   if (a.rhs_id == LSSVR_RHS_SIN)
     return launch(enhance_large_kernel<LSSVR_RHS_SIN, false>, grid, block, s, o, a, tables);
   return launch(enhance_large_kernel<LSSVR_RHS_ARRAY, false>, grid, block, s, o, a, tables);
-}
-
-hipError_t enhance_dual(const EnhanceArgs&, hipStream_t, const LaunchOpts*) {
-  return hipErrorNotSupported;
 }
 
 }  // namespace lssvr

@@ -1,0 +1,151 @@
+// Shared pieces of the wave-per-element-pair kernels (enhance_large.hip, enhance_dual.hip):
+// LDS geometry, wave-level helpers, and the in-register LDL^T factor / solve of a padded
+// 32 x 32 symmetric system held one column per lane (two systems per wave, one per
+// 32-lane half).
+#pragma once
+#include "lssvr_device.hpp"
+#include "lssvr_kernels.hpp"
+
+namespace lssvr {
+namespace wave {
+
+constexpr int kLP = 32;                 // padded size of the augmented system
+constexpr int kCH = 32;                 // collocation points per chunk
+constexpr int kSV = 34;                 // Vt column stride (doubles)
+constexpr int kSG = 33;                 // G row stride (doubles)
+constexpr int kSL = 34;                 // L row stride (even: 16-B aligned row pairs)
+constexpr int kVDoubles = kLP * kSV;    // 1088 = 32*34 >= 32*33 (G and L alias Vt)
+constexpr int kHalfDoubles = kVDoubles + 3 * kLP;   // Vt | E0 | E1 | Z
+constexpr int kWaveDoubles = 2 * kHalfDoubles;
+constexpr int kWavesPerBlock = 4;
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef double double2_t __attribute__((ext_vector_type(2)));
+
+// recurrence coefficients, index m: q_m = al2[m] t q_{m-1} - be2[m] q_{m-2} (L'' family),
+// r_m = al1[m] t r_{m-1} - be1[m] r_{m-2} (L' family)
+// L_p = alL[p] t L_{p-1} - beL[p] L_{p-2} (Legendre values)
+struct RecTables {
+  double al2[kLP + 2], be2[kLP + 2], al1[kLP + 2], be1[kLP + 2], alL[kLP + 2], beL[kLP + 2];
+};
+
+inline RecTables make_rec_tables() {
+  RecTables t{};
+  for (int m = 1; m < kLP + 2; ++m) {
+    t.al2[m] = (double)(2 * m + 3) / (double)m;
+    t.be2[m] = (double)(m + 3) / (double)m;
+    t.al1[m] = (double)(2 * m + 1) / (double)m;
+    t.be1[m] = (double)(m + 1) / (double)m;
+    t.alL[m] = (double)(2 * m - 1) / (double)m;
+    t.beL[m] = (double)(m - 1) / (double)m;
+  }
+  return t;
+}
+
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int srclane) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, srclane);
+  const unsigned hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), srclane);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+// sum over the 32 lanes of a half
+__device__ __forceinline__ double half_sum(double v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// L_p(t) for t = +-1 -/+ 2s, |s| tiny:  L_p(1-2s) = sum_k (-1)^k C(p,k) C(p+k,k) s^k
+__device__ __forceinline__ double legendre_near_one(int p, double s) {
+  constexpr double kInvSq[6] = {1.0, 1.0 / 4.0, 1.0 / 9.0, 1.0 / 16.0, 1.0 / 25.0, 1.0 / 36.0};
+  double term = 1.0, sum = 1.0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    term *= (-s * kInvSq[k]) * (double)((p - k) * (p + k + 1));
+    sum += term;
+  }
+  return sum;
+}
+
+
+// ---------------------------------------------------------------------------
+// LDL^T factor + solve.  On entry lane (c, h) holds column c of the symmetric matrix of
+// system h in col[0..31] (row index = register index); the right-hand side sits in row
+// kRhsRow of every column (and, by symmetry, is column kRhsRow).  Only the leading
+// nsys x nsys block is factorised.  Lm: this half's 32 x kSL LDS region (aliases the Gram
+// buffer), Z: 32 doubles.  Returns z_c, the solution component of lane c (0 for c >= nsys).
+//
+// Right-looking elimination without square roots: at step j the UNSCALED pivot row
+// a_jc is published through LDS (row j of Lm), every lane reads the pivot d_j = a_jj and
+// the entries a_ji it needs, and updates a_ic -= a_ji * (a_jc / d_j).  Lanes c < j publish
+// zeros, so the stored factor has an exactly zero upper triangle and the backward
+// substitution needs no lane masks.  A zero / negative / non-finite pivot makes 1/d_j
+// inf/NaN or flips signs; every later entry inherits it, so the caller's single finiteness
+// test on the solution detects a breakdown (SPD input => all d_j > 0 is also checked).
+// ---------------------------------------------------------------------------
+constexpr int kRhsRow = kLP - 1;
+
+__device__ __forceinline__ double ldlt_solve(double (&col)[kLP], double* __restrict__ Lm,
+                                             double* __restrict__ Z, int c, int nsys,
+                                             bool& pivots_ok) {
+  // (cc is an opaque copy of c: otherwise hipcc hoists all 31 lane masks (c < j) out of the
+  // caller's element loop and spills them to VGPR lanes.)
+  // (likewise ns for the 31 uniform conditions j < nsys.)
+  int cc = c;
+  asm volatile("" : "+v"(cc));
+  int ns = nsys;
+  asm volatile("" : "+s"(ns));
+  double dmin = 1.0;
+#pragma unroll
+  for (int j = 0; j < kLP - 1; ++j) {
+    if (j < ns) {
+      Lm[j * kSL + c] = (cc < j) ? 0.0 : col[j];          // unscaled pivot row a_jc
+      wave_lds_sync();
+      const double dj = Lm[j * kSL + j];
+      dmin = fmin(dmin, dj);
+      const double tcj = col[j] * rcp_newton(dj);           // a_jc / d_j
+      if ((j + 1) & 1) col[j + 1] = fma(-Lm[j * kSL + j + 1], tcj, col[j + 1]);
+#pragma unroll
+      for (int i = (j + 2) & ~1; i < kLP; i += 2) {
+        const double2_t l2 = *reinterpret_cast<const double2_t*>(&Lm[j * kSL + i]);
+        col[i] = fma(-l2[0], tcj, col[i]);
+        col[i + 1] = fma(-l2[1], tcj, col[i + 1]);
+      }
+    }
+  }
+  pivots_ok = dmin > 0.0;       // (a NaN pivot slips through fmin but poisons the solution)
+  wave_lds_sync();
+  // backward substitution: L^T z = D^{-1} L^{-1} r.  Lane t keeps Y_t = a_{rhs,t} - sum_{i>t}
+  // a_it z_i (row kRhsRow carried the forward substitution) and z_t = Y_t / d_t.
+  // (row c of the stored factor was published at step c: slot kRhsRow is the fully
+  // eliminated right-hand-side entry a_{rhs,c}, slot c the pivot d_c)
+  double Y = Lm[c * kSL + kRhsRow];
+  double rinv = rcp_newton(Lm[c * kSL + c]);
+  if (c >= nsys) {
+    Y = 0.0;
+    rinv = 0.0;
+  }
+  wave_lds_sync();
+  Lm[c * kSL + c] = 0.0;               // diagonal no longer needed: freezes Y_t after step t
+  asm volatile("" : "+s"(ns));
+#pragma unroll
+  for (int i = kLP - 2; i >= 0; --i) {
+    if (i < ns) {
+      Z[c] = Y * rinv;
+      wave_lds_sync();
+      const double zi = Z[i];
+      const double lit = Lm[c * kSL + i];   // a_ic = d_c L_ic for i > c; 0 for i <= c
+      Y = fma(-lit, zi, Y);
+    }
+  }
+  return (c < nsys) ? Y * rinv : 0.0;
+}
+
+}  // namespace wave
+}  // namespace lssvr

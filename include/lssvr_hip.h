@@ -48,9 +48,14 @@ extern "C" {
 /* per-element solver */
 #define LSSVR_SOLVER_PRIMAL 0 /* BC-eliminated primal normal equations, (M-2) SPD,
                                  Cholesky (default; <=1e-15 of the exact minimiser on
-                                 every BASELINE config)                            */
-#define LSSVR_SOLVER_DUAL   1 /* north_star's dual Gram form, (n+2) system, equilibrated
-                                 LU with partial pivoting (accuracy-gated) */
+                                 every BASELINE config).  When n_colloc < M-2 the primal
+                                 Gram is rank deficient and the call is routed to
+                                 LSSVR_SOLVER_DUAL (its limits then apply)         */
+#define LSSVR_SOLVER_DUAL   1 /* north_star's dual Gram form: K = Z Z^T + I/gamma over the
+                                 n collocation + 2 boundary rows, (n+2) LDL^T solve, w = Z^T
+                                 alpha.  n_colloc <= 29, M <= 32.  Accurate when n+2 <= M
+                                 (where PRIMAL is rank deficient); accuracy-gated otherwise,
+                                 see DESIGN.md                                          */
 #define LSSVR_SOLVER_PRIMAL_WAVE 2 /* same algorithm as PRIMAL, forced onto the
                                  wave-per-element / f64-MFMA Gram mapping whatever M is
                                  (PRIMAL picks lane-per-element for M <= 14); for A/B

@@ -99,11 +99,15 @@ def test_collocation_counts(dev, n):
     assert np.max(np.abs(W @ sgn - np.concatenate([[0.0], values[1:-1]]))) < 1e-12
     assert np.max(np.abs(W.sum(1) - np.concatenate([values[1:-1], [0.0]]))) < 1e-12
     if n < M - 2:
-        # fewer collocation points than bubble coefficients: the Gram is rank deficient and
-        # only the 1/gamma ridge (1e-13 relative here) holds the primal normal equations up;
-        # float64 cannot resolve that (DESIGN.md "limits") -- the dual solver covers this
-        # regime.  No BASELINE configuration is in it (5>=3, 12>=6, 16>=7, 64>=31, 12>=10).
+        # fewer collocation points than bubble coefficients: the primal Gram is rank deficient
+        # (float64 KKT / normal equations are O(1) wrong there, oracle included); the library
+        # routes these calls to the dual Gram solver, checked against the 60-digit minimiser.
+        # No BASELINE configuration is in this regime (5>=3, 12>=6, 16>=7, 64>=31, 12>=10).
         assert np.all(np.isfinite(W))
+        if cf.HAVE_MP:
+            sel = [0, 1, 64, 129]
+            tr = cf.truth_all(nodes, values, M, 1e4, n, orc.poisson_rhs, (-1.0, 1.0), sel)
+            assert orc.rel_l2_coef(W[sel], tr).max() <= 1e-13
         return
     Wo = orc.enhance_all_vec(nodes, values, M, 1e4, n)
     assert orc.rel_l2_coef(W, Wo).max() <= 1e-12
