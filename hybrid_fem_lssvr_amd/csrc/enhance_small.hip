@@ -90,12 +90,33 @@ __device__ __forceinline__ void enhance_small_body(const EnhanceArgs& p, const u
 #pragma unroll
       for (int i = 0; i < MR; ++i) rv[i] = 0.0;
 
+      // In-kernel rhs f = amp sin(fl(omega x_k)) without a full sin per point: the angles
+      // advance by ~omega*step, so (s~, c~) = (sin, cos)(th0 + k dth) is carried by a rotation
+      // (seeds: one sincos of th0 = fl(omega a) and one of dth = fl(omega step)), and the exact
+      // argument numpy would use, arg_k = fl(omega x_k), is restored to first order:
+      //   sin(arg_k) = s~ + c~ delta,  delta = (arg_k - th0) - k dth   (|delta| ~ |omega x| eps).
+      // delta^2/2 and the rotation's rounding (<= ~n eps) are far below the 1e-13 parity bar;
+      // a wave with any |delta| > 1e-7 (|omega x| > ~1e8) takes the per-point sin instead.
+      double rs = 0.0, rc = 1.0, sd = 0.0, cd = 1.0, th0 = 0.0, dth = 0.0;
+      if constexpr (RHS == LSSVR_RHS_SIN) {
+        th0 = p.rhs_omega * a;
+        dth = p.rhs_omega * step;
+        sincos_reduced(th0, rs, rc);
+        sincos_reduced(dth, sd, cd);
+      }
       for (int k = 0; k < n; ++k) {
         const double xk = linspace_at(a, b, dm.oldlen, step, k, n);
         const double tk = dm.off + dm.scl * xk;
         double fk;
         if constexpr (RHS == LSSVR_RHS_SIN) {
-          fk = p.rhs_amp * sin_reduced(p.rhs_omega * xk);
+          const double arg = p.rhs_omega * xk;
+          const double delta = fma(-(double)k, dth, arg - th0);
+          double sk = fma(rc, delta, rs);
+          if (__any(!(fabs(delta) < 1.0e-7))) sk = sin_reduced(arg);
+          fk = p.rhs_amp * sk;
+          const double rs_next = fma(rs, cd, rc * sd);
+          rc = fma(rc, cd, -(rs * sd));
+          rs = rs_next;
         } else {
           fk = p.rhs_values[e * n + k];
         }
@@ -213,8 +234,11 @@ __device__ __forceinline__ void enhance_small_body(const EnhanceArgs& p, const u
   }
 }
 
-template <int M, int RHS, bool VC>
-__global__ __launch_bounds__(kBlock) void enhance_small_kernel(EnhanceArgs p) {
+// MINW = minimum waves per SIMD the register allocator must leave room for.  1: no
+// constraint (fewest instructions: best when the launch has <= 2 waves per SIMD, e.g. 1e5
+// elements); 3: <= 168 VGPRs (a few spills, but a third resident wave: +6 % at >= 1e6 elements).
+template <int M, int RHS, bool VC, int MINW>
+__global__ __launch_bounds__(kBlock, MINW) void enhance_small_kernel(EnhanceArgs p) {
   __shared__ double tile[kBlock * M];
   enhance_small_body<M, RHS, VC>(p, blockIdx.x, tile);
 }
@@ -241,7 +265,14 @@ __global__ __launch_bounds__(kBlock) void step_small_kernel(EnhanceArgs p, P1Arg
 template <int M, int RHS, bool VC>
 static hipError_t launch_small(const EnhanceArgs& a, hipStream_t s, const LaunchOpts* o) {
   const unsigned blocks = (unsigned)((a.ne + kBlock - 1) / kBlock);
-  return launch(enhance_small_kernel<M, RHS, VC>, dim3(blocks), dim3(kBlock), s, o, a);
+  // more than 2 waves per SIMD on the 256-CU chip -> the occupancy-3 build pays off, but only
+  // where the kernel is within a few registers of 168 VGPRs anyway (M <= 9; at M = 12 the
+  // forced spills cost 2.3x)
+  if constexpr (M <= 9 && !VC) {
+    if (a.ne > 2 * 64 * 4 * 256)
+      return launch(enhance_small_kernel<M, RHS, VC, 3>, dim3(blocks), dim3(kBlock), s, o, a);
+  }
+  return launch(enhance_small_kernel<M, RHS, VC, 1>, dim3(blocks), dim3(kBlock), s, o, a);
 }
 
 template <int M>

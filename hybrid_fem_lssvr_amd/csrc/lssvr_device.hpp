@@ -68,6 +68,54 @@ __device__ __forceinline__ double sin_reduced(double arg) {
   return (ji & 1) ? -s : s;
 }
 
+// sin and cos of the same argument, same reduction as sin_reduced (|arg| < 3e9; callers
+// fall back to the ocml routines beyond): odd / even Taylor polynomials on [-pi/2, pi/2]
+// through r^21 / r^22 (truncation < 2e-18).
+__device__ __forceinline__ void sincos_reduced(double arg, double& s_out, double& c_out) {
+  constexpr double kInvPi = 0.31830988618379067154;
+  constexpr double kPiHi = 3.14159265358979311600e+00;
+  constexpr double kPiLo = 1.22464679914735317723e-16;
+  if (!(fabs(arg) < 3.0e9)) {
+    s_out = sin(arg);
+    c_out = cos(arg);
+    return;
+  }
+  const double j = rint(arg * kInvPi);
+  double r = fma(-j, kPiHi, arg);
+  r = fma(-j, kPiLo, r);
+  const double z = r * r;
+  double p = -1.0 / 51090942171709440000.0;             // -1/21!
+  p = fma(p, z, 1.0 / 121645100408832000.0);
+  p = fma(p, z, -1.0 / 355687428096000.0);
+  p = fma(p, z, 1.0 / 1307674368000.0);
+  p = fma(p, z, -1.0 / 6227020800.0);
+  p = fma(p, z, 1.0 / 39916800.0);
+  p = fma(p, z, -1.0 / 362880.0);
+  p = fma(p, z, 1.0 / 5040.0);
+  p = fma(p, z, -1.0 / 120.0);
+  p = fma(p, z, 1.0 / 6.0);
+  double s = fma(-(r * z), p, r);
+  double q = 1.0 / 1124000727777607680000.0;            //  1/22!
+  q = fma(q, z, -1.0 / 2432902008176640000.0);          // -1/20!
+  q = fma(q, z, 1.0 / 6402373705728000.0);              //  1/18!
+  q = fma(q, z, -1.0 / 20922789888000.0);               // -1/16!
+  q = fma(q, z, 1.0 / 87178291200.0);                   //  1/14!
+  q = fma(q, z, -1.0 / 479001600.0);                    // -1/12!
+  q = fma(q, z, 1.0 / 3628800.0);                       //  1/10!
+  q = fma(q, z, -1.0 / 40320.0);                        // -1/8!
+  q = fma(q, z, 1.0 / 720.0);                           //  1/6!
+  q = fma(q, z, -1.0 / 24.0);                           // -1/4!
+  q = fma(q, z, 0.5);                                   //  1/2!   (sign folded below)
+  double c = fma(-z, q, 1.0);
+  const long long ji = (long long)j;
+  if (ji & 1) {
+    s = -s;
+    c = -c;
+  }
+  s_out = s;
+  c_out = c;
+}
+
 // 1/sqrt(x) to ~1 ulp: hardware seed (v_rsq_f64, ~2^-26 rel.) + two Newton steps.
 __device__ __forceinline__ double rsqrt_newton(double x) {
   double y = __builtin_amdgcn_rsq(x);
