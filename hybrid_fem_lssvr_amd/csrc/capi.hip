@@ -270,6 +270,17 @@ int lssvr_tridiag_dirichlet_solve(const double* diag, const double* off, const d
                       "tridiag_dirichlet_solve");
 }
 
+int64_t lssvr_p1_flux_work_bytes(int64_t ne) { return lssvr::flux_work_bytes(ne); }
+
+int lssvr_p1_flux_solve(const double* kloc, const double* load, int64_t ne, double u0, double u1,
+                        double* u, void* work, void* stream) {
+  if (ne < 1) return fail(LSSVR_ERR_SIZE, "ne = %lld < 1", (long long)ne);
+  if (!kloc || !load || !u || !work) return fail(LSSVR_ERR_NULL, "kloc, load, u, work must be non-NULL");
+  return check_launch(lssvr::flux_dirichlet_solve(kloc, load, ne, u0, u1, u, work,
+                                                  reinterpret_cast<hipStream_t>(stream)),
+                      "flux_dirichlet_solve");
+}
+
 int lssvr_eval(const double* x, const double* W, int64_t ne, int M, const double* xq, int64_t P,
                double* uq, int64_t* elem, void* stream) {
   if (ne < 1) return fail(LSSVR_ERR_SIZE, "ne = %lld < 1", (long long)ne);

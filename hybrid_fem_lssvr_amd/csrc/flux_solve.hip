@@ -1,0 +1,159 @@
+// Dirichlet solve of the assembled P1 system by two nested prefix sums -- `enforce` +
+// `solve` (Dual.py:129-130) specialised to what Dual.py:117-128 assembles.
+//
+// The P1 stiffness matrix of -(a u')' on a line is A = D^T K D (D = nodal difference,
+// K = diag(k_e), k_e = abar_e / h_e).  With the element flux q_e = k_e (u_{e+1} - u_e), row i
+// reads q_{i-1} - q_i = load_i, hence
+//     q_e = q_0 - S_e,                 S_e = sum_{j=1..e} load_j,
+//     u_m = u_0 + q_0 R_m - T_m,       R_m = sum_{e<m} 1/k_e,  T_m = sum_{e<m} S_e / k_e,
+//     q_0 = (u_ne - u_0 + T_ne) / R_ne.
+// No elimination, so no amplification by the condition number (~ne^2) of A: the forward
+// error is that of three length-ne sums.  The three sums are ONE scan of the associative,
+// non-commutative operator on (alpha, rho, gamma):
+//     element e:  (l_e, 1/k_e, l_e/k_e),   l_0 = 0, l_e = load_e
+//     (a1,r1,g1) then (a2,r2,g2)  ->  (a1+a2, r1+r2, g1+g2 + r2*a1)
+// whose running value after element e is (S_e, R_{e+1}, T_{e+1}).
+// Three launches: block aggregates, scan of the aggregates (one workgroup), block-local scan
+// + output.  Each thread owns kItems consecutive elements.
+#include "lssvr_device.hpp"
+#include "lssvr_kernels.hpp"
+
+namespace lssvr {
+
+namespace {
+
+constexpr int kItems = 8;
+constexpr int kTile = kBlock * kItems;      // elements per workgroup
+
+struct Agg {
+  double a, r, g;
+};
+
+__device__ __forceinline__ Agg combine(const Agg& x, const Agg& y) {   // x first, then y
+  Agg o;
+  o.a = x.a + y.a;
+  o.r = x.r + y.r;
+  o.g = (x.g + y.g) + y.r * x.a;
+  return o;
+}
+
+__device__ __forceinline__ Agg elem_agg(const double* __restrict__ kloc,
+                                        const double* __restrict__ load, int64_t e) {
+  const double l = (e == 0) ? 0.0 : load[e];
+  const double rk = 1.0 / kloc[e];
+  Agg o;
+  o.a = l;
+  o.r = rk;
+  o.g = l * rk;
+  return o;
+}
+
+// exclusive scan of the 256 per-thread aggregates of a workgroup (in order), returns the
+// workgroup total in `total`
+__device__ __forceinline__ Agg block_exclusive(const Agg& mine, Agg* sh, Agg& total) {
+  const int tid = threadIdx.x;
+  sh[tid] = mine;
+  __syncthreads();
+  // Hillis-Steele inclusive scan with the non-commutative operator (left operand = earlier)
+  for (int off = 1; off < kBlock; off <<= 1) {
+    Agg v = sh[tid];
+    if (tid >= off) v = combine(sh[tid - off], v);
+    __syncthreads();
+    sh[tid] = v;
+    __syncthreads();
+  }
+  total = sh[kBlock - 1];
+  Agg ex;
+  ex.a = ex.r = ex.g = 0.0;
+  if (tid > 0) ex = sh[tid - 1];
+  __syncthreads();
+  return ex;
+}
+
+__global__ __launch_bounds__(kBlock) void flux_block_agg_kernel(const double* __restrict__ kloc,
+                                                                 const double* __restrict__ load,
+                                                                 int64_t ne, Agg* __restrict__ bagg) {
+  __shared__ Agg sh[kBlock];
+  const int64_t base = (int64_t)blockIdx.x * kTile + (int64_t)threadIdx.x * kItems;
+  Agg acc;
+  acc.a = acc.r = acc.g = 0.0;
+#pragma unroll
+  for (int i = 0; i < kItems; ++i) {
+    const int64_t e = base + i;
+    if (e < ne) acc = combine(acc, elem_agg(kloc, load, e));
+  }
+  Agg total;
+  block_exclusive(acc, sh, total);
+  if (threadIdx.x == 0) bagg[blockIdx.x] = total;
+}
+
+// one workgroup: exclusive scan of the nb block aggregates in place; the grand total goes to
+// bagg[nb]
+__global__ __launch_bounds__(kBlock) void flux_scan_agg_kernel(Agg* __restrict__ bagg, int64_t nb) {
+  __shared__ Agg sh[kBlock];
+  Agg carry;
+  carry.a = carry.r = carry.g = 0.0;
+  for (int64_t base = 0; base < nb; base += kBlock) {
+    const int64_t i = base + threadIdx.x;
+    Agg mine;
+    mine.a = mine.r = mine.g = 0.0;
+    if (i < nb) mine = bagg[i];
+    Agg total;
+    const Agg ex = block_exclusive(mine, sh, total);
+    if (i < nb) bagg[i] = combine(carry, ex);
+    carry = combine(carry, total);
+  }
+  if (threadIdx.x == 0) bagg[nb] = carry;
+}
+
+__global__ __launch_bounds__(kBlock) void flux_output_kernel(const double* __restrict__ kloc,
+                                                              const double* __restrict__ load,
+                                                              int64_t ne, const Agg* __restrict__ bagg,
+                                                              int64_t nb, double u0, double u1,
+                                                              double* __restrict__ u) {
+  __shared__ Agg sh[kBlock];
+  const Agg grand = bagg[nb];
+  const double q0 = ((u1 - u0) + grand.g) / grand.r;
+  const int64_t base = (int64_t)blockIdx.x * kTile + (int64_t)threadIdx.x * kItems;
+  Agg loc[kItems];
+  Agg acc;
+  acc.a = acc.r = acc.g = 0.0;
+#pragma unroll
+  for (int i = 0; i < kItems; ++i) {
+    const int64_t e = base + i;
+    if (e < ne) acc = combine(acc, elem_agg(kloc, load, e));
+    loc[i] = acc;                      // inclusive within the thread
+  }
+  Agg total;
+  const Agg ex = combine(bagg[blockIdx.x], block_exclusive(acc, sh, total));
+#pragma unroll
+  for (int i = 0; i < kItems; ++i) {
+    const int64_t e = base + i;
+    if (e < ne) {
+      const Agg v = combine(ex, loc[i]);                 // (S_e, R_{e+1}, T_{e+1})
+      u[e + 1] = (e + 1 == ne) ? u1 : (u0 + q0 * v.r) - v.g;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) u[0] = u0;
+}
+
+}  // namespace
+
+int64_t flux_work_bytes(int64_t ne) {
+  const int64_t nb = (ne + kTile - 1) / kTile;
+  return (nb + 2) * (int64_t)sizeof(Agg) + 64;
+}
+
+hipError_t flux_dirichlet_solve(const double* kloc, const double* load, int64_t ne, double u0,
+                                double u1, double* u, void* work, hipStream_t s) {
+  const int64_t nb = (ne + kTile - 1) / kTile;
+  Agg* bagg = reinterpret_cast<Agg*>(work);
+  hipLaunchKernelGGL(flux_block_agg_kernel, dim3((unsigned)nb), dim3(kBlock), 0, s, kloc, load, ne,
+                     bagg);
+  hipLaunchKernelGGL(flux_scan_agg_kernel, dim3(1), dim3(kBlock), 0, s, bagg, nb);
+  hipLaunchKernelGGL(flux_output_kernel, dim3((unsigned)nb), dim3(kBlock), 0, s, kloc, load, ne,
+                     bagg, nb, u0, u1, u);
+  return hipGetLastError();
+}
+
+}  // namespace lssvr

@@ -79,6 +79,10 @@ hipError_t tridiag_dirichlet_solve(const double* diag, const double* off, const 
                                    int64_t ne, double u0, double u1, double* u, void* work,
                                    hipStream_t s);
 
+int64_t flux_work_bytes(int64_t ne);
+hipError_t flux_dirichlet_solve(const double* kloc, const double* load, int64_t ne, double u0,
+                                double u1, double* u, void* work, hipStream_t s);
+
 hipError_t eval_points(const double* x, const double* W, int64_t ne, int M, const double* xq,
                        int64_t P, double* uq, int64_t* elem, hipStream_t s);
 

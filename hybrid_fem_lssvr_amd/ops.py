@@ -262,6 +262,26 @@ def tridiag_dirichlet_solve(diag, off, load, u0=0.0, u1=0.0, *, out=None, work=N
     return out
 
 
+def p1_flux_solve(kloc, load, u0=0.0, u1=0.0, *, out=None, work=None, stream=None):
+    """``enforce`` + ``solve`` (Dual.py:129-130) for the assembled P1 system through the
+    element-flux prefix scan (A = D^T K D); kloc[ne], load[ne+1] from :func:`p1_assemble`."""
+    lib = _capi.load()
+    _dev(kloc, "kloc")
+    _dev(load, "load")
+    ne = kloc.numel()
+    if load.numel() != ne + 1:
+        raise ValueError("load must have ne+1 entries")
+    if out is None:
+        out = torch.empty(ne + 1, dtype=torch.float64, device=kloc.device)
+    nbytes = lib.lssvr_p1_flux_work_bytes(ne)
+    if work is None or work.numel() * work.element_size() < nbytes:
+        work = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=kloc.device)
+    rc = lib.lssvr_p1_flux_solve(_ptr(kloc), _ptr(load), ne, float(u0), float(u1), _ptr(out),
+                                 _ptr(work), _stream(stream))
+    _capi.check(rc, "lssvr_p1_flux_solve")
+    return out
+
+
 def evaluate(x, W, xq, *, want_elem=True, stream=None):
     """``evaluate_solution`` (Dual.py:176-203) -> (u float64[P], elem int64[P] | None)."""
     lib = _capi.load()

@@ -17,7 +17,9 @@ without the HIP library or without a GPU every solve raises.
 Additions over the reference (all keyword-only, defaults reproduce the reference):
 ``n_colloc`` (hard-coded 12 at Dual.py:40), ``rhs`` (``poisson_rhs`` at Dual.py:157),
 ``nquad`` (scikit-fem's default 2-point rule for P1), ``mesh`` (a scikit-fem style
-mesh/basis or node array instead of ``np.linspace(a, b, num_fem_nodes)``).
+mesh/basis or node array instead of ``np.linspace(a, b, num_fem_nodes)``), ``fem_solver``
+(``"bands"``: the assembled float64 tridiagonal system, as ``enforce`` + ``solve`` see it;
+``"flux"``: exact-structure prefix-scan solve).
 """
 from __future__ import annotations
 
@@ -212,7 +214,7 @@ def lssvr_primal(rhs_func, domain_range, u_xmin, u_xmax, M, gamma,
 class FEMLSSVRPrimalSolver:
     def __init__(self, num_fem_nodes=5, lssvr_M=12, lssvr_gamma=1e6, global_domain=(-1, 1), *,
                  n_colloc=12, rhs=poisson_rhs, nquad=2, mesh=None, device="cuda:0",
-                 solver=ops.SOLVER_PRIMAL):
+                 solver=ops.SOLVER_PRIMAL, fem_solver="bands"):
         # Dual.py:101-108
         self.num_fem_nodes = num_fem_nodes
         self.lssvr_M = lssvr_M
@@ -228,6 +230,9 @@ class FEMLSSVRPrimalSolver:
         self.mesh = None if mesh is None else as_line_mesh(mesh)
         self.device = device
         self.solver_id = solver
+        if fem_solver not in ("bands", "flux"):
+            raise ValueError("fem_solver must be 'bands' or 'flux'")
+        self.fem_solver = fem_solver
         self.enhanced = None            # EnhancedSolution after solve_lssvr_subproblems
         self._x_dev = None
         self._u_dev = None
@@ -246,14 +251,21 @@ class FEMLSSVRPrimalSolver:
         basis = P1Basis(m)
         x = _to_dev(m.nodes, dev)
         if isinstance(self.rhs, SinRHS):
-            bands = ops.p1_assemble(x, self.nquad, rhs=(self.rhs.amp, self.rhs.omega))
+            bands = ops.p1_assemble(x, self.nquad, rhs=(self.rhs.amp, self.rhs.omega), want_local=True)
         else:
             xq = ops.quad_points(x, self.nquad)
             fq = _to_dev(self.rhs(xq.cpu().numpy()), dev)
-            bands = ops.p1_assemble(x, self.nquad, rhs_quad=fq)
-        u = ops.tridiag_dirichlet_solve(bands["diag"], bands["off"], bands["load"],
-                                        main_boundary_condition_left(self.global_domain[0]),
-                                        main_boundary_condition_right(self.global_domain[1]))
+            bands = ops.p1_assemble(x, self.nquad, rhs_quad=fq, want_local=True)
+        u0 = main_boundary_condition_left(self.global_domain[0])
+        u1 = main_boundary_condition_right(self.global_domain[1])
+        if self.fem_solver == "flux":
+            # exact-structure solution of A = D^T K D by the element-flux prefix scan
+            u = ops.p1_flux_solve(bands["kloc"], bands["load"], u0, u1)
+        else:
+            # the float64 matrix scikit-fem would assemble (rounded diagonal included), as
+            # `enforce` + `solve` see it (Dual.py:129-130)
+            u = ops.tridiag_dirichlet_solve(bands["diag"], bands["off"], bands["load"], u0, u1)
+        self.bands = bands
         self._x_dev, self._u_dev = x, u
         u_fem = u.cpu().numpy()
         self.fem_nodes = m.p[0]

@@ -192,6 +192,18 @@ int lssvr_tridiag_dirichlet_solve(const double* diag, const double* off, const d
                                   double* u, void* work, void* stream);
 
 /*
+ * lssvr_p1_flux_solve -- the same `enforce` + `solve` (Dual.py:129-130) for the P1 system
+ * that lssvr_p1_assemble produces, from the element stiffnesses kloc[ne] (k_e = abar_e/h_e)
+ * and the assembled load[ne+1]: A = D^T K D, so u follows from one prefix scan of the
+ * element fluxes (no elimination, no amplification by cond(A) ~ ne^2).  u[0] = u0,
+ * u[ne] = u1.  work: device scratch of lssvr_p1_flux_work_bytes(ne).  This is what the
+ * Python facade's solve_fem uses; lssvr_tridiag_dirichlet_solve takes arbitrary bands.
+ */
+int64_t lssvr_p1_flux_work_bytes(int64_t ne);
+int lssvr_p1_flux_solve(const double* kloc, const double* load, int64_t ne, double u0, double u1,
+                        double* u, void* work, void* stream);
+
+/*
  * lssvr_eval -- `evaluate_solution` (Dual.py:176-203): for each query point the
  * first element j with x[j] <= xq <= x[j+1] (points on an interior node take the
  * LEFT element; below/above the mesh -> element 0 / ne-1, polynomial

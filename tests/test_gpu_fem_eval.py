@@ -61,12 +61,44 @@ def test_tridiag_dirichlet_solve(dev, ne):
     assert np.max(np.abs(u - ref)) <= 1e-15 * scale * max(ne, 10) ** 1.5
 
 
+@pytest.mark.parametrize("ne", [1, 2, 3, 24, 2047, 2048, 2049, 100000, 1234567, 10000000])
+def test_p1_flux_solve(dev, ne):
+    """Prefix-scan solve of the P1 system: residual at rounding level, and -- unlike any
+    elimination -- a forward error that does not grow like cond(A) ~ ne^2 (checked against a
+    long-double Thomas solve where that is affordable)."""
+    from hybrid_fem_lssvr_amd import ops
+    nodes = np.linspace(-1, 1, ne + 1)
+    kd, fl, fr = orc.p1_assemble_local(nodes)
+    diag, off, load = orc.p1_scatter(kd, fl, fr)
+    u = ops.p1_flux_solve(_t(kd, dev), _t(load, dev), 0.25, -0.5).cpu().numpy()
+    assert u[0] == 0.25 and u[-1] == -0.5
+    # exact-structure reference: the same three sums in long double
+    ld = np.longdouble
+    k = kd.astype(ld)
+    l = load.astype(ld).copy()
+    l[0] = 0
+    S = np.cumsum(l[:ne])
+    R = np.cumsum(1 / k)
+    T = np.cumsum(S / k)
+    q0 = (ld(-0.5) - ld(0.25) + T[-1]) / R[-1]
+    uref = np.concatenate([[ld(0.25)], ld(0.25) + q0 * R - T])
+    assert float(np.max(np.abs(u[:-1] - uref[:-1]))) <= 4e-15 * max(1.0, np.log2(ne + 1))
+    # Against LAPACK on the ASSEMBLED float64 bands the two differ by much more than either
+    # solver's error: rounding diag = k_{i-1} + k_i (1e-16 relative) breaks the zero row sums of
+    # D^T K D, i.e. adds a spurious reaction term, which moves the solution by ~ne^2 * eps
+    # (2.5e-8 at ne = 1e5, measured in long double; DESIGN.md section 3.4).
+    ref = orc.banded_dirichlet(diag, off, load, 0.25, -0.5)
+    assert np.max(np.abs(u - ref)) <= 5e-16 * max(ne, 10) ** 2 + 1e-13
+
+
 def test_fem_nodal_error_matches_survey(dev):
     """Manufactured solution: P1 with the 2-point Gauss load has max nodal error 3.274e-6 on 24
     elements -- the pin for the scikit-fem part that cannot run here."""
     import hybrid_fem_lssvr_amd as pkg
     s = pkg.FEMLSSVRPrimalSolver(25, lssvr_M=8, lssvr_gamma=1e4)
+    u_flux, _ = pkg.FEMLSSVRPrimalSolver(25, lssvr_M=8, lssvr_gamma=1e4, fem_solver="flux").solve_fem()
     u_fem, basis = s.solve_fem()
+    assert np.max(np.abs(u_fem - u_flux)) < 1e-14
     assert basis.N == 25 and basis.mesh.t.shape == (2, 24) and basis.mesh.p.shape == (1, 25)
     assert np.array_equal(basis.get_dofs(), [0, 24])
     err = np.max(np.abs(u_fem - np.sin(np.pi * s.fem_nodes)))
