@@ -84,7 +84,8 @@ __device__ __forceinline__ double legendre_near_one(int p, double s) {
 // Right-looking elimination without square roots: at step j the UNSCALED pivot row
 // a_jc is published through LDS (row j of Lm), every lane reads the pivot d_j = a_jj and
 // the entries a_ji it needs, and updates a_ic -= a_ji * (a_jc / d_j).  Lanes c < j publish
-// zeros, so the stored factor has an exactly zero upper triangle and the backward
+// zeros (lane j itself publishes the pivot; its own column then cancels to zero, which is
+// harmless: a dead column is never read from registers again), so the stored factor has an exactly zero upper triangle and the backward
 // substitution needs no lane masks.  A zero / negative / non-finite pivot makes 1/d_j
 // inf/NaN or flips signs; every later entry inherits it, so the caller's single finiteness
 // test on the solution detects a breakdown (SPD input => all d_j > 0 is also checked).
@@ -102,21 +103,28 @@ __device__ __forceinline__ double ldlt_solve(double (&col)[kLP], double* __restr
   int ns = nsys;
   asm volatile("" : "+s"(ns));
   double dmin = 1.0;
+  // Software-pipelined by one step: row j+1 is published as soon as its entries are final
+  // (right after the first update of step j), so its LDS round trip overlaps the remaining
+  // 30-j updates of step j instead of stalling step j+1.
+  Lm[0 * kSL + c] = col[0];
+  wave_lds_sync();
 #pragma unroll
   for (int j = 0; j < kLP - 1; ++j) {
     if (j < ns) {
-      Lm[j * kSL + c] = (cc < j) ? 0.0 : col[j];          // unscaled pivot row a_jc
-      wave_lds_sync();
       const double dj = Lm[j * kSL + j];
       dmin = fmin(dmin, dj);
       const double tcj = col[j] * rcp_newton(dj);           // a_jc / d_j
-      if ((j + 1) & 1) col[j + 1] = fma(-Lm[j * kSL + j + 1], tcj, col[j + 1]);
+      // row j+1 of every column first, then publish it
+      col[j + 1] = fma(-Lm[j * kSL + j + 1], tcj, col[j + 1]);
+      if (j + 1 < kLP - 1) Lm[(j + 1) * kSL + c] = (cc < j + 1) ? 0.0 : col[j + 1];
+      if ((j + 2) & 1) col[j + 2] = fma(-Lm[j * kSL + j + 2], tcj, col[j + 2]);
 #pragma unroll
-      for (int i = (j + 2) & ~1; i < kLP; i += 2) {
+      for (int i = (j + 3) & ~1; i < kLP; i += 2) {
         const double2_t l2 = *reinterpret_cast<const double2_t*>(&Lm[j * kSL + i]);
         col[i] = fma(-l2[0], tcj, col[i]);
         col[i + 1] = fma(-l2[1], tcj, col[i + 1]);
       }
+      wave_lds_sync();
     }
   }
   pivots_ok = dmin > 0.0;       // (a NaN pivot slips through fmin but poisons the solution)
