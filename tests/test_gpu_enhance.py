@@ -237,3 +237,32 @@ def test_full_size_config2_properties(dev):
         sel = [0, 1, 49999, 50000, 99999]
         tr = cf.truth_all(nodes, values, M, 1e4, n, orc.poisson_rhs, (-1.0, 1.0), sel)
         assert orc.rel_l2_coef(W[sel], tr).max() <= TOL_TRUTH
+
+
+def test_full_size_config3_single_gpu(dev):
+    """BASELINE config 3's mesh (1e7 elements, degree 8, 16 points) on one GPU: every element
+    solved, boundary rows exact everywhere, a 4e4-element sample against the batched oracle and
+    a few elements against the 60-digit minimiser; shard stitching is covered by
+    test_shard_offsets_boundary_flags and tests/test_distributed_gloo.py."""
+    import torch
+    from hybrid_fem_lssvr_amd import ops
+    ne, M, n = 10000000, 9, 16
+    nodes = np.linspace(-1, 1, ne + 1)
+    values = np.sin(np.pi * nodes)
+    values[0] = values[-1] = 0.0
+    W, st = ops.enhance(_t(nodes, dev), _t(values, dev), M, 1e4, n, global_domain=(-1.0, 1.0))
+    assert int(st.sum().item()) == 0
+    sgn = torch.as_tensor((-1.0) ** np.arange(M), device=dev)
+    left = (W @ sgn).cpu().numpy()
+    right = W.sum(1).cpu().numpy()
+    assert np.max(np.abs(left - values[:-1])) < 1e-13
+    assert np.max(np.abs(right - values[1:])) < 1e-13
+    for s0 in (0, 4999000, ne - 20000):
+        sl = slice(s0, s0 + 20000)
+        Wo = orc.enhance_all_vec(nodes[s0:s0 + 20001], values[s0:s0 + 20001], M, 1e4, n,
+                                 global_domain=(-1.0, 1.0))
+        assert orc.rel_l2_coef(W[sl].cpu().numpy(), Wo).max() <= 1e-12
+    if cf.HAVE_MP:
+        sel = [0, 1, 5000000, ne - 1]
+        tr = cf.truth_all(nodes, values, M, 1e4, n, orc.poisson_rhs, (-1.0, 1.0), sel)
+        assert orc.rel_l2_coef(W[sel].cpu().numpy(), tr).max() <= TOL_TRUTH

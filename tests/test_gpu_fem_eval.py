@@ -268,3 +268,34 @@ def test_fused_step_equals_separate_launches(dev):
     dt = ops.enhance_profiled(x, u, M, 1e4, n, elem_offset=7, ne_global=ne + 20,
                               global_domain=(-3.0, 2.0), out=W3)
     assert torch.equal(W3, W2) and 1e-7 < dt < 1e-2
+
+
+def test_varcoef_config5_full_size(dev):
+    """BASELINE config 5 at its full size (1e6 elements, degree 8, 16 points, random smooth a(x)):
+    boundary rows on every element, a sample against the batched oracle and the 60-digit
+    minimiser.  No reference counterpart exists for this configuration (Dual.py:44)."""
+    import torch
+    from hybrid_fem_lssvr_amd import ops
+    c, phi = orc.varcoef_params()
+    a, da, f = orc.varcoef_functions(c, phi)
+    ne, M, n = 1000000, 9, 16
+    nodes = np.linspace(-1, 1, ne + 1)
+    values = np.sin(np.pi * nodes)
+    values[0] = values[-1] = 0.0
+    x = _t(nodes, dev)
+    xc = ops.colloc_points(x, n).cpu().numpy()
+    W, st = ops.enhance_varcoef(x, _t(values, dev), M, 1e4, n, _t(a(xc), dev), _t(da(xc), dev),
+                                _t(f(xc), dev), global_domain=(-1.0, 1.0))
+    assert int(st.sum().item()) == 0
+    W = W.cpu().numpy()
+    sgn = (-1.0) ** np.arange(M)
+    assert np.max(np.abs(W @ sgn - values[:-1])) < 1e-12
+    assert np.max(np.abs(W.sum(1) - values[1:])) < 1e-12
+    for s0 in (0, 600000, ne - 5000):
+        Wo = orc.enhance_all_vec(nodes[s0:s0 + 5001], values[s0:s0 + 5001], M, 1e4, n, rhs=f,
+                                 coef_a=a, coef_da=da, global_domain=(-1.0, 1.0))
+        assert orc.rel_l2_coef(W[s0:s0 + 5000], Wo).max() <= 1e-11
+    if cf.HAVE_MP:
+        sel = [0, 333333, ne - 1]
+        tr = cf.truth_all(nodes, values, M, 1e4, n, f, (-1.0, 1.0), sel, coef_a=a, coef_da=da)
+        assert orc.rel_l2_coef(W[sel], tr).max() <= 1e-13
