@@ -299,3 +299,33 @@ def test_varcoef_config5_full_size(dev):
         sel = [0, 333333, ne - 1]
         tr = cf.truth_all(nodes, values, M, 1e4, n, f, (-1.0, 1.0), sel, coef_a=a, coef_da=da)
         assert orc.rel_l2_coef(W[sel], tr).max() <= 1e-13
+
+
+def test_step_is_hip_graph_capturable(dev):
+    """include/lssvr_hip.h promises every call is asynchronous on the caller's stream and safe
+    to capture: record the fused step + evaluation into a hipGraph, replay it on new nodal
+    values, compare with eager launches."""
+    import torch
+    from hybrid_fem_lssvr_amd import ops
+    ne, M, n = 4096, 9, 16
+    nodes = np.linspace(-1, 1, ne + 1)
+    x = _t(nodes, dev)
+    u = _t(np.sin(np.pi * nodes), dev)
+    xq = _t(np.linspace(-1, 1, 1001), dev)
+    plan = ops.StepPlan(x, u, M, 1e4, n, global_domain=(-1.0, 1.0))
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        plan.launch()                      # warm-up outside capture
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        plan.launch()
+        uq_g, _ = ops.evaluate(x, plan.W, xq, want_elem=False)
+    u.copy_(_t(np.cos(nodes), dev))        # new input, same buffers
+    g.replay()
+    torch.cuda.synchronize()
+    W_g, uq_graph = plan.W.clone(), uq_g.clone()
+    W_e, _ = ops.enhance(x, u, M, 1e4, n, global_domain=(-1.0, 1.0))
+    uq_e, _ = ops.evaluate(x, W_e, xq, want_elem=False)
+    assert torch.equal(W_g, W_e) and torch.equal(uq_graph, uq_e)
