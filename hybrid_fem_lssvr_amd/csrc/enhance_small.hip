@@ -11,7 +11,7 @@
 //      r += rho * phi -- the Legendre Gram contraction over collocation points;
 //   4. the two boundary rows L_p(t_a), L_p(t_b), eliminated analytically:
 //      w_{0,1} = d - C v;
-//   5. S = G + eps (I + C^T C), Cholesky, two triangular solves;
+//   5. S = G + eps (I + C^T C), LDL^T, two triangular solves;
 //   6. status / linear-interpolant fallback (Dual.py:164-169).
 // Each wave transposes its 64 x M coefficient tile through (wave-private) LDS so that
 // the store to W[ne, M] (row-major, 8*M B per element) is fully coalesced.
@@ -72,8 +72,11 @@ __device__ __forceinline__ void enhance_small_body(const EnhanceArgs& p, const u
       d1 = (gr - gl) * idet;
 #pragma unroll
       for (int j = 0; j < MR; ++j) {
-        C0[j] = (tb * La[j + 2] - ta * Lb[j + 2]) * idet;
-        C1[j] = (Lb[j + 2] - La[j + 2]) * idet;
+        // Poisson rows work in the rescaled unknowns v' = D v (see legendre_d2_scaled):
+        // C' = C D^-1, so w_{0,1} = d - C v = d - C' v'
+        const double sc = VC ? idet : idet * (1.0 / d2_scale(j));
+        C0[j] = (tb * La[j + 2] - ta * Lb[j + 2]) * sc;
+        C1[j] = (Lb[j + 2] - La[j + 2]) * sc;
       }
     };
     if constexpr (VC || MR == 0) boundary_rows();
@@ -121,7 +124,8 @@ __device__ __forceinline__ void enhance_small_body(const EnhanceArgs& p, const u
           fk = p.rhs_values[e * n + k];
         }
         double rho[MR];
-        legendre_d2<MR>(tk, rho);
+        if constexpr (VC) legendre_d2<MR>(tk, rho);
+        else legendre_d2_scaled<MR>(tk, rho);
         double phi = -(fk * inv_scl2);
         if constexpr (VC) {
           const double ak = p.a_values[e * n + k];
@@ -147,29 +151,30 @@ __device__ __forceinline__ void enhance_small_body(const EnhanceArgs& p, const u
 #pragma unroll
         for (int j = 0; j <= i; ++j) {
           double cc = fma(C0[i], C0[j], C1[i] * C1[j]);
-          if (i == j) cc += 1.0;
+          if (i == j) cc += VC ? 1.0 : 1.0 / (d2_scale(i) * d2_scale(i));   // eps D^-2 on the diagonal
           G[tri(i, j)] = fma(eps, cc, G[tri(i, j)]);
         }
         rv[i] = fma(eps, fma(C0[i], d0, C1[i] * d1), rv[i]);
       }
 
-      // --- Cholesky (lower, in place; diagonal holds 1/L_jj).  No diagonal pre-scaling:
-      // Cholesky is invariant under symmetric diagonal scaling up to rounding (measured:
-      // same <=2e-16 distance to the 60-digit minimiser with and without).
-      // A non-positive / non-finite pivot becomes NaN in rsqrt and reaches every later
-      // entry, so the finiteness test on the solution catches a breakdown.
+      // --- LDL^T (lower, in place; unit L below the diagonal, diagonal holds 1/d_j).  No
+      // square roots, no diagonal pre-scaling: elimination of an SPD matrix is invariant
+      // under symmetric diagonal scaling up to rounding (measured: same <=2e-16 distance to
+      // the 60-digit minimiser).  A zero / non-finite pivot turns into inf / NaN
+      // in 1/d_j and reaches every later entry; a negative one is caught by the sign test.
       bool ok = true;
 #pragma unroll
       for (int j = 0; j < MR; ++j) {
-        const double linv = rsqrt_newton(G[tri(j, j)]);
-        G[tri(j, j)] = linv;
-#pragma unroll
-        for (int i = j + 1; i < MR; ++i) G[tri(i, j)] *= linv;
+        ok = ok && (G[tri(j, j)] > 0.0);
+        const double rinv = rcp_newton(G[tri(j, j)]);
+        G[tri(j, j)] = rinv;
 #pragma unroll
         for (int c = j + 1; c < MR; ++c) {
+          const double lcj = G[tri(c, j)] * rinv;              // L_cj = a_cj / d_j
 #pragma unroll
           for (int i = c; i < MR; ++i)
-            G[tri(i, c)] = fma(-G[tri(i, j)], G[tri(c, j)], G[tri(i, c)]);
+            G[tri(i, c)] = fma(-G[tri(i, j)], lcj, G[tri(i, c)]);
+          G[tri(c, j)] = lcj;     // column j below the diagonal now holds L (rows <= c are done)
         }
       }
       // forward  L y = rhs
@@ -178,22 +183,22 @@ __device__ __forceinline__ void enhance_small_body(const EnhanceArgs& p, const u
         double s = rv[i];
 #pragma unroll
         for (int j = 0; j < i; ++j) s = fma(-G[tri(i, j)], rv[j], s);
-        rv[i] = s * G[tri(i, i)];
+        rv[i] = s;
       }
-      // backward L^T z = y
+      // backward L^T z = D^-1 y
 #pragma unroll
       for (int i = MR - 1; i >= 0; --i) {
-        double s = rv[i];
+        double s = rv[i] * G[tri(i, i)];
 #pragma unroll
         for (int j = i + 1; j < MR; ++j) s = fma(-G[tri(j, i)], rv[j], s);
-        rv[i] = s * G[tri(i, i)];
+        rv[i] = s;
       }
       // w_{0,1} = d - C v
       double w0 = d0, w1 = d1;
 #pragma unroll
       for (int j = 0; j < MR; ++j) {
-        const double v = rv[j];
-        w[j + 2] = v;
+        const double v = rv[j];                                   // v'_j (rescaled unknowns)
+        w[j + 2] = VC ? v : v * (1.0 / d2_scale(j));
         w0 = fma(-C0[j], v, w0);
         w1 = fma(-C1[j], v, w1);
         ok = ok && (fabs(v) < 1.0e300);

@@ -158,6 +158,22 @@ hipError_t eval_points(const double* x, const double* W, int64_t ne, int M, cons
 // ---------------------------------------------------------------------------
 // FP64 peak probe
 // ---------------------------------------------------------------------------
+// use_mfma >= 100: VALU probe with only the first (use_mfma - 100) lanes of every wave active
+// (does a partially masked wave64 FP64 instruction cost fewer cycles?)
+__global__ __launch_bounds__(kBlock) void fp64_fma_masked_probe_kernel(double* out, int iters,
+                                                                        int active) {
+  const int tid = blockIdx.x * kBlock + threadIdx.x;
+  if ((threadIdx.x & 63) >= active) return;
+  double a0 = 1.0 + tid * 1e-9, a1 = a0 + 0.1, a2 = a0 + 0.2, a3 = a0 + 0.3;
+  double a4 = a0 + 0.4, a5 = a0 + 0.5, a6 = a0 + 0.6, a7 = a0 + 0.7;
+  const double m = 0.999999, c = 1e-7;
+  for (int i = 0; i < iters; ++i) {
+    a0 = fma(a0, m, c); a1 = fma(a1, m, c); a2 = fma(a2, m, c); a3 = fma(a3, m, c);
+    a4 = fma(a4, m, c); a5 = fma(a5, m, c); a6 = fma(a6, m, c); a7 = fma(a7, m, c);
+  }
+  out[tid] = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+}
+
 __global__ __launch_bounds__(kBlock) void fp64_fma_probe_kernel(double* out, int iters) {
   const int tid = blockIdx.x * kBlock + threadIdx.x;
   double a0 = 1.0 + tid * 1e-9, a1 = a0 + 0.1, a2 = a0 + 0.2, a3 = a0 + 0.3;
@@ -203,7 +219,10 @@ hipError_t stream_probe(const double* src, double* dst, int64_t n, hipStream_t s
 }
 
 hipError_t fp64_probe(double* out, int blocks, int iters, int use_mfma, hipStream_t s) {
-  if (use_mfma)
+  if (use_mfma >= 100)
+    hipLaunchKernelGGL(fp64_fma_masked_probe_kernel, dim3(blocks), dim3(kBlock), 0, s, out, iters,
+                       use_mfma - 100);
+  else if (use_mfma)
     hipLaunchKernelGGL(fp64_mfma_probe_kernel, dim3(blocks), dim3(kBlock), 0, s, out, iters);
   else
     hipLaunchKernelGGL(fp64_fma_probe_kernel, dim3(blocks), dim3(kBlock), 0, s, out, iters);

@@ -150,6 +150,28 @@ __device__ __forceinline__ void legendre_d2(double t, double (&q)[MR]) {
   }
 }
 
+// The same family rescaled so that the recurrence needs one multiply less per term:
+//   q_m = c_m p_m,  c_0 = c_1 = 1,  c_m = c_{m-2} (m+3)/m   =>   p_m = A_m t p_{m-1} - p_{m-2},
+//   A_m = (2m+3) c_{m-1} / (m c_m).
+// Working with p instead of q is a diagonal change of variables of the (M-2) system:
+// G' = D^-1 G D^-1, v' = D v, D = diag(c) (enhance_small.hip folds D into the boundary
+// block and the final coefficients).
+__host__ __device__ constexpr double d2_scale(int m) {
+  double c = 1.0;
+  for (int i = m; i >= 2; i -= 2) c *= (double)(i + 3) / (double)i;
+  return c;
+}
+__host__ __device__ constexpr double d2_coef(int m) {
+  return (double)(2 * m + 3) * d2_scale(m - 1) / ((double)m * d2_scale(m));
+}
+template <int MR>
+__device__ __forceinline__ void legendre_d2_scaled(double t, double (&p)[MR]) {
+  if constexpr (MR > 0) p[0] = 3.0;
+  if constexpr (MR > 1) p[1] = 15.0 * t;
+#pragma unroll
+  for (int m = 2; m < MR; ++m) p[m] = fma(d2_coef(m) * t, p[m - 1], -p[m - 2]);
+}
+
 // r[m] = L'_{m+1}(t) = C^{(3/2)}_m(t):  r0 = 1, r1 = 3 t,
 //   m r_m = (2m+1) t r_{m-1} - (m+1) r_{m-2}
 template <int MD>
