@@ -329,3 +329,17 @@ def test_step_is_hip_graph_capturable(dev):
     W_e, _ = ops.enhance(x, u, M, 1e4, n, global_domain=(-1.0, 1.0))
     uq_e, _ = ops.evaluate(x, W_e, xq, want_elem=False)
     assert torch.equal(W_g, W_e) and torch.equal(uq_graph, uq_e)
+
+
+def test_c_abi_demo_program(dev):
+    """examples/c_abi_demo.cpp drives the whole solve-then-enhance path through the C ABI alone
+    (hipMalloc'd buffers, no Python, no torch) and checks the reference demo's error figures."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "c_abi_demo")
+    if not os.path.exists(exe):
+        pytest.fail("examples/c_abi_demo missing: run __graft_entry__.build()")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "OK" in r.stdout
