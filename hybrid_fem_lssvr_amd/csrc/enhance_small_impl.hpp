@@ -1,0 +1,322 @@
+// Per-element LSSVR enhancement, lane-per-element path (2 <= M <= 22): ONE ELEMENT PER
+// LANE, the whole (M-2)x(M-2) system register-resident (VGPRs up to M = 14, VGPRs + AGPRs
+// at one wave per SIMD up to M = 22 -- still 4x (M = 20) to 1.7x (M = 22) faster than the
+// wave-cooperative mapping of enhance_large.hip; the crossover is at M = 23).
+//
+// What one lane computes (DESIGN.md "per-element solve"; oracle restatement:
+// oracle/lssvr_oracle.py::solve_bc_eliminated; reference: Dual.py:20-98):
+//   1. element data a=x[e], b=x[e+1], g_l, g_r (Dual.py:143-151, 65-75);
+//   2. numpy's domain map and collocation abscissae, two-rounding arithmetic
+//      (Dual.py:40,56 -> linspace / mapparms / mapdomain);
+//   3. for every collocation point: f(x_k), the row rho_j = L''_{j+2}(t_k)
+//      (Gegenbauer recurrence) and the rank-1 updates G += rho rho^T,
+//      r += rho * phi -- the Legendre Gram contraction over collocation points;
+//   4. the two boundary rows L_p(t_a), L_p(t_b), eliminated analytically:
+//      w_{0,1} = d - C v;
+//   5. S = G + eps (I + C^T C), LDL^T, two triangular solves;
+//   6. status / linear-interpolant fallback (Dual.py:164-169).
+// Each wave transposes its 64 x M coefficient tile through (wave-private) LDS so that
+// the store to W[ne, M] (row-major, 8*M B per element) is fully coalesced.
+//
+// Why lane-per-element rather than a wave-cooperative factorisation: the system
+// is 7x7 at degree 8; 28 Gram entries + 7 rhs fit in ~90 VGPRs, every operation
+// is lane-local (no cross-lane traffic, no LDS in the loop, no divergence), and
+// all 64 lanes do useful FP64 work.  Measured numbers: DESIGN.md.
+#pragma once
+#include "lssvr_device.hpp"
+#include "lssvr_kernels.hpp"
+#include "lssvr_p1.hpp"
+
+namespace lssvr {
+
+template <int M, int RHS, bool VC>
+__device__ __forceinline__ void enhance_small_body(const EnhanceArgs& p, const unsigned block,
+                                                   double* __restrict__ tile) {
+  constexpr int MR = M - 2;
+  constexpr int NT = MR * (MR + 1) / 2;
+
+  const int tid = threadIdx.x;
+  const int64_t e = (int64_t)block * kBlock + tid;
+  double w[M];
+  int st = LSSVR_ST_OK;
+#pragma unroll
+  for (int i = 0; i < M; ++i) w[i] = 0.0;
+
+  if (e < p.ne) {
+    const double a = p.x[e];
+    const double b = p.x[e + 1];
+    const int64_t eg = e + p.elem_offset;
+    // Dual.py:65-75: Dirichlet value only on a global-boundary element whose end
+    // point equals the global end point exactly
+    const double gl = (eg == 0 && a == p.gxmin) ? p.bc_left : p.u[e];
+    const double gr = (eg == p.ne_global - 1 && b == p.gxmax) ? p.bc_right : p.u[e + 1];
+
+    const DomainMap dm = map_params(a, b);
+    const int n = p.n;
+    const double step = dm.oldlen / (double)(n - 1);
+    const double scl2 = dm.scl * dm.scl;
+    const double inv_scl2 = rcp_newton(scl2);
+    const double eps = rcp_newton(p.gamma * (scl2 * scl2));   // 1 / (gamma * scl^4)
+
+    // --- boundary rows (Dual.py:61-76): B = [L_p(t_a); L_p(t_b)], eliminated as
+    // w_{0,1} = d - C v with B1 = [[1, ta], [1, tb]], B1^{-1} = [[tb, -ta], [-1, 1]]/(tb - ta).
+    // The variable-coefficient rows need C inside the Gram loop; the Poisson rows do
+    // not, so there the block runs after the loop (64 fewer live VGPRs in the loop).
+    double d0 = 0.0, d1 = 0.0;
+    double C0[MR > 0 ? MR : 1], C1[MR > 0 ? MR : 1];
+    auto boundary_rows = [&]() {
+      const double ta = dm.off + dm.scl * a;
+      const double tb = dm.off + dm.scl * b;
+      double La[M], Lb[M];
+      legendre_p<M>(ta, La);
+      legendre_p<M>(tb, Lb);
+      const double idet = rcp_newton(tb - ta);
+      d0 = (tb * gl - ta * gr) * idet;
+      d1 = (gr - gl) * idet;
+#pragma unroll
+      for (int j = 0; j < MR; ++j) {
+        // Poisson rows work in the rescaled unknowns v' = D v (see legendre_d2_scaled):
+        // C' = C D^-1, so w_{0,1} = d - C v = d - C' v'
+        const double sc = VC ? idet : idet * (1.0 / d2_scale(j));
+        C0[j] = (tb * La[j + 2] - ta * Lb[j + 2]) * sc;
+        C1[j] = (Lb[j + 2] - La[j + 2]) * sc;
+      }
+    };
+    if constexpr (VC || MR == 0) boundary_rows();
+
+    if constexpr (MR == 0) {
+      w[0] = d0;
+      w[1] = d1;
+      if (!(isfinite(d0) && isfinite(d1))) st = LSSVR_ST_FALLBACK;
+    } else {
+      // --- Gram contraction over the collocation points ------------------------
+      double G[NT], rv[MR];
+#pragma unroll
+      for (int i = 0; i < NT; ++i) G[i] = 0.0;
+#pragma unroll
+      for (int i = 0; i < MR; ++i) rv[i] = 0.0;
+
+      // In-kernel rhs f = amp sin(fl(omega x_k)) without a full sin per point: the angles
+      // advance by ~omega*step, so (s~, c~) = (sin, cos)(th0 + k dth) is carried by a rotation
+      // (seeds: one sincos of th0 = fl(omega a) and one of dth = fl(omega step)), and the exact
+      // argument numpy would use, arg_k = fl(omega x_k), is restored to first order:
+      //   sin(arg_k) = s~ + c~ delta,  delta = (arg_k - th0) - k dth   (|delta| ~ |omega x| eps).
+      // delta^2/2 and the rotation's rounding (<= ~n eps) are far below the 1e-13 parity bar;
+      // a wave with any |delta| > 1e-7 (|omega x| > ~1e8) takes the per-point sin instead.
+      double rs = 0.0, rc = 1.0, sd = 0.0, cd = 1.0, th0 = 0.0, dth = 0.0;
+      if constexpr (RHS == LSSVR_RHS_SIN) {
+        th0 = p.rhs_omega * a;
+        dth = p.rhs_omega * step;
+        sincos_reduced(th0, rs, rc);
+        sincos_reduced(dth, sd, cd);
+      }
+      for (int k = 0; k < n; ++k) {
+        const double xk = linspace_at(a, b, dm.oldlen, step, k, n);
+        const double tk = dm.off + dm.scl * xk;
+        double fk;
+        if constexpr (RHS == LSSVR_RHS_SIN) {
+          const double arg = p.rhs_omega * xk;
+          const double delta = fma(-(double)k, dth, arg - th0);
+          double sk = fma(rc, delta, rs);
+          if (__any(!(fabs(delta) < 1.0e-7))) sk = sin_reduced(arg);
+          fk = p.rhs_amp * sk;
+          const double rs_next = fma(rs, cd, rc * sd);
+          rc = fma(rc, cd, -(rs * sd));
+          rs = rs_next;
+        } else {
+          fk = p.rhs_values[e * n + k];
+        }
+        double rho[MR];
+        if constexpr (VC) legendre_d2<MR>(tk, rho);
+        else legendre_d2_scaled<MR>(tk, rho);
+        double phi = -(fk * inv_scl2);
+        if constexpr (VC) {
+          const double ak = p.a_values[e * n + k];
+          const double bk = p.da_values[e * n + k] / dm.scl;
+          double r1[MR + 1];
+          legendre_d1<MR + 1>(tk, r1);        // r1[m] = L'_{m+1}; need L'_{j+2} = r1[j+1]
+#pragma unroll
+          for (int j = 0; j < MR; ++j) rho[j] = fma(ak, rho[j], bk * (r1[j + 1] - C1[j]));
+          phi = -fma(bk, d1, fk * inv_scl2);
+        }
+#pragma unroll
+        for (int i = 0; i < MR; ++i) {
+#pragma unroll
+          for (int j = 0; j <= i; ++j) G[tri(i, j)] = fma(rho[i], rho[j], G[tri(i, j)]);
+          rv[i] = fma(rho[i], phi, rv[i]);
+        }
+      }
+
+      if constexpr (!VC) boundary_rows();
+      // --- S = G + eps (I + C^T C),  rhs = r + eps C^T d --------------------------
+#pragma unroll
+      for (int i = 0; i < MR; ++i) {
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+          double cc = fma(C0[i], C0[j], C1[i] * C1[j]);
+          if (i == j) cc += VC ? 1.0 : 1.0 / (d2_scale(i) * d2_scale(i));   // eps D^-2 on the diagonal
+          G[tri(i, j)] = fma(eps, cc, G[tri(i, j)]);
+        }
+        rv[i] = fma(eps, fma(C0[i], d0, C1[i] * d1), rv[i]);
+      }
+
+      // --- LDL^T (lower, in place; unit L below the diagonal, diagonal holds 1/d_j).  No
+      // square roots, no diagonal pre-scaling: elimination of an SPD matrix is invariant
+      // under symmetric diagonal scaling up to rounding (measured: same <=2e-16 distance to
+      // the 60-digit minimiser).  A zero / non-finite pivot turns into inf / NaN
+      // in 1/d_j and reaches every later entry; a negative one is caught by the sign test.
+      bool ok = true;
+#pragma unroll
+      for (int j = 0; j < MR; ++j) {
+        ok = ok && (G[tri(j, j)] > 0.0);
+        const double rinv = rcp_newton(G[tri(j, j)]);
+        G[tri(j, j)] = rinv;
+#pragma unroll
+        for (int c = j + 1; c < MR; ++c) {
+          const double lcj = G[tri(c, j)] * rinv;              // L_cj = a_cj / d_j
+#pragma unroll
+          for (int i = c; i < MR; ++i)
+            G[tri(i, c)] = fma(-G[tri(i, j)], lcj, G[tri(i, c)]);
+          G[tri(c, j)] = lcj;     // column j below the diagonal now holds L (rows <= c are done)
+        }
+      }
+      // forward  L y = rhs
+#pragma unroll
+      for (int i = 0; i < MR; ++i) {
+        double s = rv[i];
+#pragma unroll
+        for (int j = 0; j < i; ++j) s = fma(-G[tri(i, j)], rv[j], s);
+        rv[i] = s;
+      }
+      // backward L^T z = D^-1 y
+#pragma unroll
+      for (int i = MR - 1; i >= 0; --i) {
+        double s = rv[i] * G[tri(i, i)];
+#pragma unroll
+        for (int j = i + 1; j < MR; ++j) s = fma(-G[tri(j, i)], rv[j], s);
+        rv[i] = s;
+      }
+      // w_{0,1} = d - C v
+      double w0 = d0, w1 = d1;
+#pragma unroll
+      for (int j = 0; j < MR; ++j) {
+        const double v = rv[j];                                   // v'_j (rescaled unknowns)
+        w[j + 2] = VC ? v : v * (1.0 / d2_scale(j));
+        w0 = fma(-C0[j], v, w0);
+        w1 = fma(-C1[j], v, w1);
+        ok = ok && (fabs(v) < 1.0e300);
+      }
+      w[0] = w0;
+      w[1] = w1;
+      ok = ok && (fabs(w0) < 1.0e300) && (fabs(w1) < 1.0e300);
+      if (!ok) st = LSSVR_ST_FALLBACK;
+    }
+
+    if (st != LSSVR_ST_OK) {
+      // Dual.py:164-169: linear interpolant of (g_l, g_r) as a Legendre series
+#pragma unroll
+      for (int i = 0; i < M; ++i) w[i] = 0.0;
+      w[0] = 0.5 * (gl + gr);
+      w[1] = 0.5 * (gr - gl);
+      if (p.fail_count) atomicAdd(p.fail_count, 1);
+    }
+    if (p.status) p.status[e] = st;
+  }
+
+  // --- coalesced store: each wave transposes its own 64 x M tile through LDS --------
+  // (wave-private, so no workgroup barrier: a wave that finishes early stores early;
+  // LDS operations of one wave execute in order)
+  const int lane = tid & 63;
+  double* const wt = tile + (tid >> 6) * (64 * M);
+#pragma unroll
+  for (int i = 0; i < M; ++i) wt[lane * M + i] = w[i];
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int64_t base = ((int64_t)block * kBlock + (tid & ~63)) * M;
+  const int64_t total = p.ne * M;
+#pragma unroll
+  for (int i = 0; i < M; ++i) {
+    const int64_t idx = base + (int64_t)i * 64 + lane;
+    // write-once output: non-temporal stores leave less for the end-of-kernel L2 write-back
+    if (idx < total) __builtin_nontemporal_store(wt[i * 64 + lane], &p.W[idx]);
+  }
+}
+
+// MINW = minimum waves per SIMD the register allocator must leave room for.  1: no
+// constraint (fewest instructions: best when the launch has <= 2 waves per SIMD, e.g. 1e5
+// elements); 3: <= 168 VGPRs (a few spills, but a third resident wave: +6 % at >= 1e6 elements).
+template <int M, int RHS, bool VC, int MINW>
+__global__ __launch_bounds__(kBlock, MINW) void enhance_small_kernel(EnhanceArgs p) {
+  __shared__ double tile[kBlock * M];
+  enhance_small_body<M, RHS, VC>(p, blockIdx.x, tile);
+}
+
+// One launch for a whole step of the hot path on one mesh: blocks [0, eblocks) run the
+// per-element enhancement, the remaining blocks the element-local P1 assembly (one thread
+// per node).  The two halves share nothing but the node array, so fusing them only removes
+// a launch boundary and lets the short assembly run in the shadow of the enhancement.
+template <int M>
+__global__ __launch_bounds__(kBlock) void step_small_kernel(EnhanceArgs p, P1Args a, QuadRule q,
+                                                             unsigned eblocks) {
+  __shared__ double tile[kBlock * M];
+  if (blockIdx.x < eblocks) {
+    enhance_small_body<M, LSSVR_RHS_SIN, false>(p, blockIdx.x, tile);
+  } else {
+    const int64_t i = (int64_t)(blockIdx.x - eblocks) * kBlock + threadIdx.x;
+    if (i <= a.ne) p1_node<true>(a, q, i);
+  }
+}
+
+// ----------------------------------------------------------------------------
+// dispatch
+// ----------------------------------------------------------------------------
+template <int M, int RHS, bool VC>
+static hipError_t launch_small(const EnhanceArgs& a, hipStream_t s, const LaunchOpts* o) {
+  const unsigned blocks = (unsigned)((a.ne + kBlock - 1) / kBlock);
+  // more than 2 waves per SIMD on the 256-CU chip -> the occupancy-3 build pays off, but only
+  // where the kernel is within a few registers of 168 VGPRs anyway (M <= 9; at M = 12 the
+  // forced spills cost 2.3x)
+  if constexpr (M <= 9 && !VC) {
+    if (a.ne > 2 * 64 * 4 * 256)
+      return launch(enhance_small_kernel<M, RHS, VC, 3>, dim3(blocks), dim3(kBlock), s, o, a);
+  }
+  return launch(enhance_small_kernel<M, RHS, VC, 1>, dim3(blocks), dim3(kBlock), s, o, a);
+}
+
+template <int M>
+static hipError_t launch_step(const EnhanceArgs& e, const P1Args& a, const QuadRule& q,
+                              hipStream_t s, const LaunchOpts* o) {
+  const unsigned eb = (unsigned)((e.ne + kBlock - 1) / kBlock);
+  const unsigned ab = (unsigned)((a.ne + 1 + kBlock - 1) / kBlock);
+  return launch(step_small_kernel<M>, dim3(eb + ab), dim3(kBlock), s, o, e, a, q, eb);
+}
+
+// Each translation unit enhance_small_*.hip instantiates a range of M (the fully unrolled
+// kernels are large: one TU per range keeps the build parallel) through this macro.
+#define LSSVR_DEFINE_SMALL_RANGE(NAME, FOR_EACH_M)                                              \
+  hipError_t enhance_small_##NAME(const EnhanceArgs& a, hipStream_t s, const LaunchOpts* o) {    \
+    switch (a.M) {                                                                               \
+      FOR_EACH_M(LSSVR_SMALL_CASE_ENH)                                                           \
+      default:                                                                                   \
+        return hipErrorInvalidValue;                                                             \
+    }                                                                                            \
+  }                                                                                              \
+  hipError_t step_small_##NAME(const EnhanceArgs& e, const P1Args& a, const QuadRule& q,         \
+                               hipStream_t s, const LaunchOpts* o) {                             \
+    switch (e.M) {                                                                               \
+      FOR_EACH_M(LSSVR_SMALL_CASE_STEP)                                                          \
+      default:                                                                                   \
+        return hipErrorInvalidValue;                                                             \
+    }                                                                                            \
+  }
+
+#define LSSVR_SMALL_CASE_ENH(MM)                                                     \
+  case MM:                                                                           \
+    if (a.a_values) return launch_small<MM, LSSVR_RHS_ARRAY, true>(a, s, o);         \
+    if (a.rhs_id == LSSVR_RHS_SIN) return launch_small<MM, LSSVR_RHS_SIN, false>(a, s, o); \
+    return launch_small<MM, LSSVR_RHS_ARRAY, false>(a, s, o);
+#define LSSVR_SMALL_CASE_STEP(MM) \
+  case MM:                        \
+    return launch_step<MM>(e, a, q, s, o);
+
+}  // namespace lssvr

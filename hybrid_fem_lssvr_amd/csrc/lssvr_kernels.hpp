@@ -7,7 +7,7 @@
 
 namespace lssvr {
 
-constexpr int kSmallMaxM = 14;   // lane-per-element path: M-2 <= 12 register-resident
+constexpr int kSmallMaxM = 22;   // lane-per-element path: (M-2)(M-1)/2 Gram entries in VGPRs + AGPRs
 constexpr int kLargeMaxM = 33;   // wave-per-element MFMA path: M-2 bubble coefficients + rhs <= 32
 
 struct EnhanceArgs {

@@ -58,7 +58,7 @@ extern "C" {
                                  see DESIGN.md                                          */
 #define LSSVR_SOLVER_PRIMAL_WAVE 2 /* same algorithm as PRIMAL, forced onto the
                                  wave-per-element / f64-MFMA Gram mapping whatever M is
-                                 (PRIMAL picks lane-per-element for M <= 14); for A/B
+                                 (PRIMAL picks lane-per-element for M <= 22); for A/B
                                  measurements of the two mappings */
 
 /* per-element status written to status[e] */

@@ -40,15 +40,17 @@ def test_golden_degree32(dev, golden):
     assert orc.rel_l2_coef(Wsel, g["coef_ref"]).max() <= TOL_REF
 
 
-@pytest.mark.parametrize("M", [15, 16, 17, 18, 19, 24, 31, 32, 33])
+@pytest.mark.parametrize("M", [15, 16, 17, 18, 19, 23, 24, 31, 32, 33])
 def test_large_degrees_vs_oracle(dev, M):
     rng = np.random.default_rng(500 + M)
     ne = 203
     nodes = np.cumsum(np.concatenate([[-0.7], rng.uniform(0.01, 0.08, ne)]))
     values = np.sin(np.pi * nodes) + 0.01 * rng.standard_normal(ne + 1)
-    n = {15: 16, 16: 31, 17: 32, 18: 33, 19: 40, 24: 64, 31: 65, 32: 96, 33: 64}[M]
+    n = {15: 16, 16: 31, 17: 32, 18: 33, 19: 40, 23: 48, 24: 64, 31: 65, 32: 96, 33: 64}[M]
     gd = (nodes[0], nodes[-1])
-    W, st = _enhance(dev, nodes, values, M, 1e4, n, global_domain=gd)
+    from hybrid_fem_lssvr_amd import ops
+    # M <= 22 would take the lane kernel by default: force the wave / MFMA mapping here
+    W, st = _enhance(dev, nodes, values, M, 1e4, n, global_domain=gd, solver=ops.SOLVER_PRIMAL_WAVE)
     assert np.all(st == 0)
     Wo = orc.enhance_all_vec(nodes, values, M, 1e4, n, global_domain=gd)
     err = orc.rel_l2_coef(W, Wo)
@@ -59,11 +61,11 @@ def test_large_degrees_vs_oracle(dev, M):
         assert orc.rel_l2_coef(W[sel], tr).max() <= TOL_TRUTH
 
 
-@pytest.mark.parametrize("M", [2, 3, 5, 9, 14])
+@pytest.mark.parametrize("M", [2, 3, 5, 9, 14, 18, 22])
 def test_wave_mapping_matches_lane_mapping(dev, M):
     """The two mappings of the same algorithm (solver 0 vs 2) agree to rounding."""
     from hybrid_fem_lssvr_amd import ops
-    ne, n = 1500, 16
+    ne, n = 1500, max(16, 2 * M)
     nodes = np.linspace(-1, 1, ne + 1)
     values = orc.fem_p1_solve(nodes)
     W0, s0 = _enhance(dev, nodes, values, M, 1e4, n)
@@ -81,7 +83,8 @@ def test_boundary_rows_general_recurrence_branch(dev):
     nodes = 1.0e6 + 1.0e-4 * np.arange(ne + 1)
     values = np.cos(np.arange(ne + 1) * 0.1)
     gd = (nodes[0], nodes[-1])
-    W, st = _enhance(dev, nodes, values, M, 1e4, n, global_domain=gd)
+    from hybrid_fem_lssvr_amd import ops
+    W, st = _enhance(dev, nodes, values, M, 1e4, n, global_domain=gd, solver=ops.SOLVER_PRIMAL_WAVE)
     Wo = orc.enhance_all_vec(nodes, values, M, 1e4, n, global_domain=gd)
     ok = st == 0
     assert ok.sum() >= ne - 2
@@ -110,7 +113,7 @@ def test_full_size_config4_sample(dev):
 def test_fallback_status_large(dev):
     import torch
     from hybrid_fem_lssvr_amd import ops
-    ne, M, n = 40, 20, 32
+    ne, M, n = 40, 24, 32
     nodes = np.linspace(0, 1, ne + 1)
     nodes[11] = nodes[10]
     values = np.sin(nodes)

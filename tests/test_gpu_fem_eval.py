@@ -158,7 +158,7 @@ def test_varcoef_config5(dev):
     from hybrid_fem_lssvr_amd import ops
     c, phi = orc.varcoef_params()
     a, da, f = orc.varcoef_functions(c, phi)
-    for ne, M, n in ((2000, 9, 16), (300, 20, 32)):
+    for ne, M, n in ((2000, 9, 16), (300, 20, 32), (100, 26, 40)):      # lane, lane (AGPR), wave
         nodes = np.linspace(-1, 1, ne + 1)
         values = orc.fem_p1_solve(nodes, rhs=f, coef_a=a)
         x = _t(nodes, dev)
