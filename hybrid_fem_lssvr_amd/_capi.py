@@ -61,6 +61,7 @@ SIGNATURES = {
     "lssvr_p1_flux_work_bytes": (_c_i64, [_c_i64]),
     "lssvr_p1_flux_solve": (_c_int, [_c_dp, _c_dp, _c_i64, _c_dbl, _c_dbl, _c_dp, _c_dp, _c_dp]),
     "lssvr_eval": (_c_int, [_c_dp, _c_dp, _c_i64, _c_int, _c_dp, _c_i64, _c_dp, _c_dp, _c_dp]),
+    "lssvr_eval_error": (_c_int, [_c_dp, _c_dp, _c_i64, _c_int, _c_dp, _c_i64, C.POINTER(_c_dbl), _c_dp, _c_dp]),
     "lssvr_fp64_probe": (_c_int, [_c_dp, _c_int, _c_int, _c_int, _c_dp]),
     "lssvr_stream_probe": (_c_int, [_c_dp, _c_dp, _c_i64, _c_dp]),
 }

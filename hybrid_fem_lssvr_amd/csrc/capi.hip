@@ -292,6 +292,19 @@ int lssvr_eval(const double* x, const double* W, int64_t ne, int M, const double
                       "eval_points");
 }
 
+int lssvr_eval_error(const double* x, const double* W, int64_t ne, int M, const double* xq,
+                     int64_t P, const double* exact_params_host, double* out3, void* stream) {
+  if (ne < 1) return fail(LSSVR_ERR_SIZE, "ne = %lld < 1", (long long)ne);
+  if (P < 0) return fail(LSSVR_ERR_SIZE, "P < 0");
+  if (M < 1) return fail(LSSVR_ERR_DEGREE, "M = %d < 1", M);
+  if (!x || !W || !out3 || !exact_params_host || (P > 0 && !xq))
+    return fail(LSSVR_ERR_NULL, "x, W, xq, exact_params, out3 must be non-NULL");
+  return check_launch(lssvr::eval_error(x, W, ne, M, xq, P, exact_params_host[0],
+                                        exact_params_host[1], out3,
+                                        reinterpret_cast<hipStream_t>(stream)),
+                      "eval_error");
+}
+
 int lssvr_stream_probe(const double* src, double* dst, int64_t n, void* stream) {
   if (!src || !dst) return fail(LSSVR_ERR_NULL, "src and dst must be non-NULL");
   if (n < 1) return fail(LSSVR_ERR_SIZE, "n must be >= 1");

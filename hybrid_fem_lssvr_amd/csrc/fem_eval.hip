@@ -104,22 +104,17 @@ __device__ __forceinline__ int64_t locate(const double* __restrict__ x, int64_t 
   return j < 0 ? 0 : (j > ne - 1 ? ne - 1 : j);
 }
 
-__global__ __launch_bounds__(kBlock) void eval_kernel(const double* __restrict__ x,
-                                                       const double* __restrict__ W, int64_t ne,
-                                                       int M, const double* __restrict__ xq,
-                                                       int64_t P, double* __restrict__ uq,
-                                                       int64_t* __restrict__ elem) {
-  const double x0 = x[0];
-  const double inv_h = (double)ne / (x[ne] - x0);
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < P;
-       i += (int64_t)gridDim.x * kBlock) {
-    const double xi = xq[i];
-    if (xi != xi) {  // NaN: no branch of Dual.py:182-201 fires, the zero stays
-      uq[i] = 0.0;
-      if (elem) elem[i] = -1;
-      continue;
-    }
+// value of the hybrid solution at one point (Dual.py:182-201); j_out = element used (-1: NaN)
+__device__ __forceinline__ double eval_point(const double* __restrict__ x,
+                                             const double* __restrict__ W, int64_t ne, int M,
+                                             double xi, double x0, double inv_h, int64_t& j_out) {
+  if (xi != xi) {  // NaN: no branch of Dual.py:182-201 fires, the zero stays
+    j_out = -1;
+    return 0.0;
+  }
+  {
     const int64_t j = locate(x, ne, xi, x0, inv_h);
+    j_out = j;
     const DomainMap dm = map_params(x[j], x[j + 1]);
     const double t = dm.off + dm.scl * xi;      // mapdomain, two roundings
     const double* c = W + j * M;
@@ -142,9 +137,79 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(const double* __restrict__
         c1 = tmp + ((c1 * t) * (double)(2 * nd - 1)) / (double)nd;
       }
     }
-    uq[i] = c0 + c1 * t;
+    return c0 + c1 * t;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void eval_kernel(const double* __restrict__ x,
+                                                       const double* __restrict__ W, int64_t ne,
+                                                       int M, const double* __restrict__ xq,
+                                                       int64_t P, double* __restrict__ uq,
+                                                       int64_t* __restrict__ elem) {
+  const double x0 = x[0];
+  const double inv_h = (double)ne / (x[ne] - x0);
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < P;
+       i += (int64_t)gridDim.x * kBlock) {
+    int64_t j;
+    uq[i] = eval_point(x, W, ne, M, xq[i], x0, inv_h, j);
     if (elem) elem[i] = j;
   }
+}
+
+// Error norms of the hybrid solution against amp*sin(omega x) (Dual.py:216-217 computes
+// `computed_solution` and `exact_solution` on the test points):
+// out[0] += sum (u - ex)^2, out[1] += sum ex^2, out[2] = max(out[2], max |u - ex|).
+// One partial per workgroup (LDS tree), then three atomics per workgroup.
+__global__ __launch_bounds__(kBlock) void eval_error_kernel(const double* __restrict__ x,
+                                                             const double* __restrict__ W,
+                                                             int64_t ne, int M,
+                                                             const double* __restrict__ xq, int64_t P,
+                                                             double amp, double omega,
+                                                             double* __restrict__ out) {
+  __shared__ double sh[3][kBlock];
+  const double x0 = x[0];
+  const double inv_h = (double)ne / (x[ne] - x0);
+  double se = 0.0, sx = 0.0, mx = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < P;
+       i += (int64_t)gridDim.x * kBlock) {
+    const double xi = xq[i];
+    int64_t j;
+    const double u = eval_point(x, W, ne, M, xi, x0, inv_h, j);
+    if (j < 0) continue;
+    const double ex = amp * sin_reduced(omega * xi);
+    const double d = u - ex;
+    se = fma(d, d, se);
+    sx = fma(ex, ex, sx);
+    mx = fmax(mx, fabs(d));
+  }
+  sh[0][threadIdx.x] = se;
+  sh[1][threadIdx.x] = sx;
+  sh[2][threadIdx.x] = mx;
+  __syncthreads();
+  for (int off = kBlock / 2; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      sh[0][threadIdx.x] += sh[0][threadIdx.x + off];
+      sh[1][threadIdx.x] += sh[1][threadIdx.x + off];
+      sh[2][threadIdx.x] = fmax(sh[2][threadIdx.x], sh[2][threadIdx.x + off]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    atomicAdd(&out[0], sh[0][0]);
+    atomicAdd(&out[1], sh[1][0]);
+    // non-negative doubles order like their bit patterns
+    atomicMax(reinterpret_cast<unsigned long long*>(&out[2]),
+              (unsigned long long)__double_as_longlong(sh[2][0]));
+  }
+}
+
+hipError_t eval_error(const double* x, const double* W, int64_t ne, int M, const double* xq,
+                      int64_t P, double amp, double omega, double* out, hipStream_t s) {
+  if (P == 0) return hipSuccess;
+  const int64_t b = (P + kBlock - 1) / kBlock;
+  hipLaunchKernelGGL(eval_error_kernel, dim3((unsigned)(b < 2048 ? b : 2048)), dim3(kBlock), 0, s, x,
+                     W, ne, M, xq, P, amp, omega, out);
+  return hipGetLastError();
 }
 
 hipError_t eval_points(const double* x, const double* W, int64_t ne, int M, const double* xq,

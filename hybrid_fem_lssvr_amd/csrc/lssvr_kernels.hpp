@@ -86,6 +86,9 @@ hipError_t flux_dirichlet_solve(const double* kloc, const double* load, int64_t 
 hipError_t eval_points(const double* x, const double* W, int64_t ne, int M, const double* xq,
                        int64_t P, double* uq, int64_t* elem, hipStream_t s);
 
+hipError_t eval_error(const double* x, const double* W, int64_t ne, int M, const double* xq,
+                      int64_t P, double amp, double omega, double* out, hipStream_t s);
+
 hipError_t fp64_probe(double* out, int blocks, int iters, int use_mfma, hipStream_t s);
 hipError_t stream_probe(const double* src, double* dst, int64_t n, hipStream_t s);
 

@@ -301,6 +301,27 @@ def evaluate(x, W, xq, *, want_elem=True, stream=None):
     return uq, elem
 
 
+def eval_error(x, W, xq, *, exact=(1.0, math.pi), out=None, stream=None):
+    """Device-side error norms of the hybrid solution vs exact(x) = amp*sin(omega*x) on xq
+    (Dual.py:216-217 + 8-9): returns a device double[3] = [sum (u-ex)^2, sum ex^2, max |u-ex|]
+    (accumulated into ``out`` when given, e.g. across shards)."""
+    lib = _capi.load()
+    _dev(x, "x")
+    _dev(W, "W")
+    _dev(xq, "xq")
+    ne = x.numel() - 1
+    if W.dim() != 2 or W.shape[0] != ne:
+        raise ValueError("W must be [ne, M]")
+    if out is None:
+        out = torch.zeros(3, dtype=torch.float64, device=x.device)
+    else:
+        _dev(out, "out")
+    rc = lib.lssvr_eval_error(_ptr(x), _ptr(W), ne, int(W.shape[1]), _ptr(xq), xq.numel(),
+                              _capi.rhs_params(*exact), _ptr(out), _stream(stream))
+    _capi.check(rc, "lssvr_eval_error")
+    return out
+
+
 def fp64_probe(blocks=4096, iters=4096, use_mfma=False, *, device="cuda:0", reps=5):
     """Measured FP64 FMA (or f64 MFMA) rate in TFLOP/s -- the roofline's compute peak."""
     lib = _capi.load()

@@ -215,6 +215,19 @@ int lssvr_eval(const double* x, const double* W, int64_t ne, int M,
                const double* xq, int64_t P, double* uq, int64_t* elem, void* stream);
 
 /*
+ * lssvr_eval_error -- error norms of the hybrid solution against the exact solution
+ * ex(x) = p[0] * sin(p[1] * x) on the query points (Dual.py:216-217 evaluates
+ * `computed_solution` and `exact_solution = true_solution(test_points)`, Dual.py:8-9:
+ * p = {1, pi}); reductions on the device, the query values never leave HBM:
+ *   out3[0] += sum (u - ex)^2,  out3[1] += sum ex^2,  out3[2] = max(out3[2], max |u - ex|).
+ * out3 is a DEVICE double[3] the caller zeroes first (accumulates across calls / shards);
+ * NaN query points are skipped, like in lssvr_eval.
+ */
+int lssvr_eval_error(const double* x, const double* W, int64_t ne, int M,
+                     const double* xq, int64_t P, const double* exact_params_host,
+                     double* out3, void* stream);
+
+/*
  * lssvr_fp64_probe -- FP64 FMA throughput microbenchmark used to quote the
  * roofline peak: runs `iters` dependent-free fused multiply-adds per lane on
  * `blocks` x 256 threads; out[blocks*256] receives a checksum.  flops = 2 * 8 *

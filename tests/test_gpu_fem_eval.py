@@ -343,3 +343,28 @@ def test_c_abi_demo_program(dev):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "OK" in r.stdout
+
+
+def test_eval_error_norms_on_device(dev):
+    """lssvr_eval_error: L2 / max error against sin(pi x) reduced on the device == the host
+    computation of Dual.py:216-217 on the same points (reference demo: rel-L2 3.255e-06)."""
+    import torch
+    import hybrid_fem_lssvr_amd as pkg
+    from hybrid_fem_lssvr_amd import ops
+    s = pkg.FEMLSSVRPrimalSolver(25, lssvr_M=8, lssvr_gamma=1e4)
+    s.solve()
+    xq_h = np.concatenate([np.linspace(-1, 1, 201), [np.nan]])
+    xq = _t(xq_h, dev)
+    out = ops.eval_error(s.enhanced.nodes, s.enhanced.W, xq).cpu().numpy()
+    u = s.evaluate_solution(xq_h[:-1])
+    ex = np.sin(np.pi * xq_h[:-1])
+    # (u - ex) ~ 3e-6 while ex itself carries ~1e-16 of sin rounding: 1e-10 relative on the sum
+    assert abs(out[0] - np.sum((u - ex) ** 2)) <= 1e-9 * np.sum((u - ex) ** 2)
+    assert abs(out[1] - np.sum(ex ** 2)) <= 1e-13 * np.sum(ex ** 2)
+    assert abs(out[2] - np.max(np.abs(u - ex))) <= 1e-15 + 1e-9 * out[2]
+    assert abs(np.sqrt(out[0] / out[1]) - 3.255e-6) < 5e-9
+    # accumulation across calls (shards): second call adds to the same buffer
+    acc = torch.zeros(3, dtype=torch.float64, device=dev)
+    ops.eval_error(s.enhanced.nodes, s.enhanced.W, xq[:100].contiguous(), out=acc)
+    ops.eval_error(s.enhanced.nodes, s.enhanced.W, xq[100:].contiguous(), out=acc)
+    assert np.allclose(acc.cpu().numpy(), out, rtol=1e-12, atol=0)
