@@ -18,6 +18,12 @@ from .solver import (  # noqa: F401
     poisson_rhs,
     true_solution,
 )
-from .distributed import ShardPlan, allgather_rows, enhance_sharded  # noqa: F401
+from .distributed import (  # noqa: F401
+    ShardPlan,
+    allgather_rows,
+    enhance_sharded,
+    solve_fem_sharded,
+    solve_sharded,
+)
 
 __version__ = "0.1.0"

@@ -60,6 +60,9 @@ SIGNATURES = {
                                                _c_dp, _c_dp, _c_dp]),
     "lssvr_p1_flux_work_bytes": (_c_i64, [_c_i64]),
     "lssvr_p1_flux_solve": (_c_int, [_c_dp, _c_dp, _c_i64, _c_dbl, _c_dbl, _c_dp, _c_dp, _c_dp]),
+    "lssvr_p1_flux_aggregate": (_c_int, [_c_dp, _c_dp, _c_i64, _c_int, _c_dp, _c_dp, _c_dp]),
+    "lssvr_p1_flux_finish": (_c_int, [_c_dp, _c_dp, _c_i64, _c_int, _c_int, _c_dp, _c_dp, _c_dp,
+                                      _c_dbl, _c_dbl, _c_dp, _c_dp]),
     "lssvr_eval": (_c_int, [_c_dp, _c_dp, _c_i64, _c_int, _c_dp, _c_i64, _c_dp, _c_dp, _c_dp]),
     "lssvr_eval_error": (_c_int, [_c_dp, _c_dp, _c_i64, _c_int, _c_dp, _c_i64, C.POINTER(_c_dbl), _c_dp, _c_dp]),
     "lssvr_fp64_probe": (_c_int, [_c_dp, _c_int, _c_int, _c_int, _c_dp]),

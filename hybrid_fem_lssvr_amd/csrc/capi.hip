@@ -281,6 +281,26 @@ int lssvr_p1_flux_solve(const double* kloc, const double* load, int64_t ne, doub
                       "flux_dirichlet_solve");
 }
 
+int lssvr_p1_flux_aggregate(const double* kloc, const double* load, int64_t ne, int first_global,
+                            void* work, double* agg3, void* stream) {
+  if (ne < 1) return fail(LSSVR_ERR_SIZE, "ne = %lld < 1", (long long)ne);
+  if (!kloc || !load || !work || !agg3) return fail(LSSVR_ERR_NULL, "kloc, load, work, agg3 must be non-NULL");
+  return check_launch(lssvr::flux_aggregate(kloc, load, ne, first_global != 0, work, agg3,
+                                            reinterpret_cast<hipStream_t>(stream)),
+                      "flux_aggregate");
+}
+
+int lssvr_p1_flux_finish(const double* kloc, const double* load, int64_t ne, int first_global,
+                         int last_global, const void* work, const double* prefix3,
+                         const double* grand3, double u0, double u1, double* u, void* stream) {
+  if (ne < 1) return fail(LSSVR_ERR_SIZE, "ne = %lld < 1", (long long)ne);
+  if (!kloc || !load || !work || !u) return fail(LSSVR_ERR_NULL, "kloc, load, work, u must be non-NULL");
+  return check_launch(lssvr::flux_finish(kloc, load, ne, first_global != 0, last_global != 0, work,
+                                         prefix3, grand3, u0, u1, u,
+                                         reinterpret_cast<hipStream_t>(stream)),
+                      "flux_finish");
+}
+
 int lssvr_eval(const double* x, const double* W, int64_t ne, int M, const double* xq, int64_t P,
                double* uq, int64_t* elem, void* stream) {
   if (ne < 1) return fail(LSSVR_ERR_SIZE, "ne = %lld < 1", (long long)ne);

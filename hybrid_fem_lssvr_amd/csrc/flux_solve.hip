@@ -15,6 +15,10 @@
 // whose running value after element e is (S_e, R_{e+1}, T_{e+1}).
 // Three launches: block aggregates, scan of the aggregates (one workgroup), block-local scan
 // + output.  Each thread owns kItems consecutive elements.
+// Sharded meshes: the operator being associative, a rank's shard contributes one aggregate
+// (flux_aggregate); the exclusive combination of the lower ranks' aggregates and the grand
+// total (24 bytes per rank through one all-gather) are all flux_finish needs -- the global
+// solve shards with a single tiny collective.
 #include "lssvr_device.hpp"
 #include "lssvr_kernels.hpp"
 
@@ -37,9 +41,12 @@ __device__ __forceinline__ Agg combine(const Agg& x, const Agg& y) {   // x firs
   return o;
 }
 
+// first_global: local element 0 is the mesh's first element (its left node is the Dirichlet
+// node, l_0 = 0); on a later shard of a sharded mesh the node's load counts.
 __device__ __forceinline__ Agg elem_agg(const double* __restrict__ kloc,
-                                        const double* __restrict__ load, int64_t e) {
-  const double l = (e == 0) ? 0.0 : load[e];
+                                        const double* __restrict__ load, int64_t e,
+                                        bool first_global) {
+  const double l = (e == 0 && first_global) ? 0.0 : load[e];
   const double rk = 1.0 / kloc[e];
   Agg o;
   o.a = l;
@@ -72,7 +79,8 @@ __device__ __forceinline__ Agg block_exclusive(const Agg& mine, Agg* sh, Agg& to
 
 __global__ __launch_bounds__(kBlock) void flux_block_agg_kernel(const double* __restrict__ kloc,
                                                                  const double* __restrict__ load,
-                                                                 int64_t ne, Agg* __restrict__ bagg) {
+                                                                 int64_t ne, bool first_global,
+                                                                 Agg* __restrict__ bagg) {
   __shared__ Agg sh[kBlock];
   const int64_t base = (int64_t)blockIdx.x * kTile + (int64_t)threadIdx.x * kItems;
   Agg acc;
@@ -80,7 +88,7 @@ __global__ __launch_bounds__(kBlock) void flux_block_agg_kernel(const double* __
 #pragma unroll
   for (int i = 0; i < kItems; ++i) {
     const int64_t e = base + i;
-    if (e < ne) acc = combine(acc, elem_agg(kloc, load, e));
+    if (e < ne) acc = combine(acc, elem_agg(kloc, load, e, first_global));
   }
   Agg total;
   block_exclusive(acc, sh, total);
@@ -89,7 +97,8 @@ __global__ __launch_bounds__(kBlock) void flux_block_agg_kernel(const double* __
 
 // one workgroup: exclusive scan of the nb block aggregates in place; the grand total goes to
 // bagg[nb]
-__global__ __launch_bounds__(kBlock) void flux_scan_agg_kernel(Agg* __restrict__ bagg, int64_t nb) {
+__global__ __launch_bounds__(kBlock) void flux_scan_agg_kernel(Agg* __restrict__ bagg, int64_t nb,
+                                                                double* __restrict__ agg_out) {
   __shared__ Agg sh[kBlock];
   Agg carry;
   carry.a = carry.r = carry.g = 0.0;
@@ -103,16 +112,41 @@ __global__ __launch_bounds__(kBlock) void flux_scan_agg_kernel(Agg* __restrict__
     if (i < nb) bagg[i] = combine(carry, ex);
     carry = combine(carry, total);
   }
-  if (threadIdx.x == 0) bagg[nb] = carry;
+  if (threadIdx.x == 0) {
+    bagg[nb] = carry;
+    if (agg_out) {
+      agg_out[0] = carry.a;
+      agg_out[1] = carry.r;
+      agg_out[2] = carry.g;
+    }
+  }
 }
 
 __global__ __launch_bounds__(kBlock) void flux_output_kernel(const double* __restrict__ kloc,
                                                               const double* __restrict__ load,
-                                                              int64_t ne, const Agg* __restrict__ bagg,
-                                                              int64_t nb, double u0, double u1,
+                                                              int64_t ne, bool first_global,
+                                                              bool last_global,
+                                                              const Agg* __restrict__ bagg,
+                                                              int64_t nb,
+                                                              const double* __restrict__ prefix3,
+                                                              const double* __restrict__ grand3,
+                                                              double u0, double u1,
                                                               double* __restrict__ u) {
   __shared__ Agg sh[kBlock];
-  const Agg grand = bagg[nb];
+  // running value before this shard and over the whole mesh (single shard: zero / own total)
+  Agg pre;
+  pre.a = pre.r = pre.g = 0.0;
+  if (prefix3) {
+    pre.a = prefix3[0];
+    pre.r = prefix3[1];
+    pre.g = prefix3[2];
+  }
+  Agg grand = bagg[nb];
+  if (grand3) {
+    grand.a = grand3[0];
+    grand.r = grand3[1];
+    grand.g = grand3[2];
+  }
   const double q0 = ((u1 - u0) + grand.g) / grand.r;
   const int64_t base = (int64_t)blockIdx.x * kTile + (int64_t)threadIdx.x * kItems;
   Agg loc[kItems];
@@ -121,20 +155,20 @@ __global__ __launch_bounds__(kBlock) void flux_output_kernel(const double* __res
 #pragma unroll
   for (int i = 0; i < kItems; ++i) {
     const int64_t e = base + i;
-    if (e < ne) acc = combine(acc, elem_agg(kloc, load, e));
+    if (e < ne) acc = combine(acc, elem_agg(kloc, load, e, first_global));
     loc[i] = acc;                      // inclusive within the thread
   }
   Agg total;
-  const Agg ex = combine(bagg[blockIdx.x], block_exclusive(acc, sh, total));
+  const Agg ex = combine(pre, combine(bagg[blockIdx.x], block_exclusive(acc, sh, total)));
 #pragma unroll
   for (int i = 0; i < kItems; ++i) {
     const int64_t e = base + i;
     if (e < ne) {
       const Agg v = combine(ex, loc[i]);                 // (S_e, R_{e+1}, T_{e+1})
-      u[e + 1] = (e + 1 == ne) ? u1 : (u0 + q0 * v.r) - v.g;
+      u[e + 1] = (e + 1 == ne && last_global) ? u1 : (u0 + q0 * v.r) - v.g;
     }
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) u[0] = u0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) u[0] = first_global ? u0 : (u0 + q0 * pre.r) - pre.g;
 }
 
 }  // namespace
@@ -144,16 +178,31 @@ int64_t flux_work_bytes(int64_t ne) {
   return (nb + 2) * (int64_t)sizeof(Agg) + 64;
 }
 
-hipError_t flux_dirichlet_solve(const double* kloc, const double* load, int64_t ne, double u0,
-                                double u1, double* u, void* work, hipStream_t s) {
+hipError_t flux_aggregate(const double* kloc, const double* load, int64_t ne, bool first_global,
+                          void* work, double* agg3, hipStream_t s) {
   const int64_t nb = (ne + kTile - 1) / kTile;
   Agg* bagg = reinterpret_cast<Agg*>(work);
   hipLaunchKernelGGL(flux_block_agg_kernel, dim3((unsigned)nb), dim3(kBlock), 0, s, kloc, load, ne,
-                     bagg);
-  hipLaunchKernelGGL(flux_scan_agg_kernel, dim3(1), dim3(kBlock), 0, s, bagg, nb);
-  hipLaunchKernelGGL(flux_output_kernel, dim3((unsigned)nb), dim3(kBlock), 0, s, kloc, load, ne,
-                     bagg, nb, u0, u1, u);
+                     first_global, bagg);
+  hipLaunchKernelGGL(flux_scan_agg_kernel, dim3(1), dim3(kBlock), 0, s, bagg, nb, agg3);
   return hipGetLastError();
+}
+
+hipError_t flux_finish(const double* kloc, const double* load, int64_t ne, bool first_global,
+                       bool last_global, const void* work, const double* prefix3,
+                       const double* grand3, double u0, double u1, double* u, hipStream_t s) {
+  const int64_t nb = (ne + kTile - 1) / kTile;
+  const Agg* bagg = reinterpret_cast<const Agg*>(work);
+  hipLaunchKernelGGL(flux_output_kernel, dim3((unsigned)nb), dim3(kBlock), 0, s, kloc, load, ne,
+                     first_global, last_global, bagg, nb, prefix3, grand3, u0, u1, u);
+  return hipGetLastError();
+}
+
+hipError_t flux_dirichlet_solve(const double* kloc, const double* load, int64_t ne, double u0,
+                                double u1, double* u, void* work, hipStream_t s) {
+  hipError_t e = flux_aggregate(kloc, load, ne, true, work, nullptr, s);
+  if (e != hipSuccess) return e;
+  return flux_finish(kloc, load, ne, true, true, work, nullptr, nullptr, u0, u1, u, s);
 }
 
 }  // namespace lssvr

@@ -86,6 +86,12 @@ hipError_t flux_dirichlet_solve(const double* kloc, const double* load, int64_t 
 hipError_t eval_points(const double* x, const double* W, int64_t ne, int M, const double* xq,
                        int64_t P, double* uq, int64_t* elem, hipStream_t s);
 
+hipError_t flux_aggregate(const double* kloc, const double* load, int64_t ne, bool first_global,
+                          void* work, double* agg3, hipStream_t s);
+hipError_t flux_finish(const double* kloc, const double* load, int64_t ne, bool first_global,
+                       bool last_global, const void* work, const double* prefix3,
+                       const double* grand3, double u0, double u1, double* u, hipStream_t s);
+
 hipError_t eval_error(const double* x, const double* W, int64_t ne, int M, const double* xq,
                       int64_t P, double amp, double omega, double* out, hipStream_t s);
 

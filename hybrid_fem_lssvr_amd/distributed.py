@@ -174,3 +174,64 @@ def enhance_sharded(x_local, u_local, plan, rank, M, gamma, n_colloc=12, *, glob
     Wg = allgather_rows(W_buf, plan, rank, group=group, chunks=chunks, out=out,
                         compute_chunk=compute)
     return W_buf[:n_loc], status, Wg
+
+
+# --------------------------------------------------------------------------
+# sharded P1 solve: assemble locally (one halo node on the left), one 24-byte all-gather
+# --------------------------------------------------------------------------
+def combine_flux(a, b):
+    """(a1,r1,g1) o (a2,r2,g2) = (a1+a2, r1+r2, g1+g2 + r2*a1): the associative operator of
+    csrc/flux_solve.hip on [..., 3] tensors (a first, then b)."""
+    return torch.stack([a[..., 0] + b[..., 0], a[..., 1] + b[..., 1],
+                        (a[..., 2] + b[..., 2]) + b[..., 1] * a[..., 0]], dim=-1)
+
+
+def solve_fem_sharded(x_ext, plan, rank, *, nquad=2, rhs=None, u0=0.0, u1=0.0, group=None):
+    """``solve_fem`` (Dual.py:110-137) on a sharded mesh without gathering it anywhere.
+
+    x_ext: this rank's nodes ``plan.node_slice(rank)`` PLUS one halo node on the left when
+    rank > 0 (the load of the shard's first node needs the element left of it).  The global
+    Dirichlet solve is the flux prefix scan: every shard contributes one (alpha, rho, gamma)
+    aggregate, all-gathered (24 bytes per rank), combined in rank order.
+    Returns (u_local float64[size+1] for the shard's own nodes, bands of the extended shard).
+    """
+    from . import ops
+
+    s0, s1 = plan.bounds(rank)
+    halo = 1 if s0 > 0 else 0
+    n_loc = s1 - s0
+    if x_ext.numel() != n_loc + 1 + halo:
+        raise ValueError(f"rank {rank}: expected {n_loc + 1 + halo} nodes (shard + left halo)")
+    kw = {} if rhs is None else {"rhs": rhs}
+    bands = ops.p1_assemble(x_ext, nquad, want_local=True, **kw)
+    kloc = bands["kloc"][halo:]
+    load = bands["load"][halo:]
+    agg, work = ops.p1_flux_aggregate(kloc, load, first_global=(s0 == 0))
+    world = plan.world
+    if world > 1:
+        allagg = torch.empty((world, 3), dtype=torch.float64, device=agg.device)
+        dist.all_gather_into_tensor(allagg.view(-1), agg, group=group)
+    else:
+        allagg = agg.view(1, 3)
+    prefix = torch.zeros(3, dtype=torch.float64, device=agg.device)
+    grand = torch.zeros(3, dtype=torch.float64, device=agg.device)
+    for r in range(world):
+        if r == rank:
+            prefix = grand.clone()
+        grand = combine_flux(grand, allagg[r])
+    u = ops.p1_flux_finish(kloc, load, work, first_global=(s0 == 0), last_global=(s1 == plan.ne),
+                           prefix=prefix, grand=grand, u0=u0, u1=u1)
+    return u, bands
+
+
+def solve_sharded(x_ext, plan, rank, M, gamma, n_colloc=12, *, global_domain, nquad=2, rhs=None,
+                  bc=(0.0, 0.0), group=None, chunks=4, gather=True):
+    """Solve-then-enhance (Dual.py:171-174) on a sharded mesh: sharded P1 solve, rank-local
+    enhancement, optional all-gather of W.  Returns (u_local, W_local, status, W_global|None)."""
+    s0, _ = plan.bounds(rank)
+    halo = 1 if s0 > 0 else 0
+    u, _ = solve_fem_sharded(x_ext, plan, rank, nquad=nquad, rhs=rhs, u0=bc[0], u1=bc[1], group=group)
+    Wl, st, Wg = enhance_sharded(x_ext[halo:], u, plan, rank, M, gamma, n_colloc,
+                                 global_domain=global_domain, rhs=rhs, bc=bc, group=group,
+                                 chunks=chunks, gather=gather)
+    return u, Wl, st, Wg

@@ -282,6 +282,42 @@ def p1_flux_solve(kloc, load, u0=0.0, u1=0.0, *, out=None, work=None, stream=Non
     return out
 
 
+def p1_flux_aggregate(kloc, load, *, first_global, work=None, stream=None):
+    """Shard summary of the flux scan: returns (agg3 device double[3], work) -- see
+    ``lssvr_p1_flux_aggregate``; ``work`` must be passed on to :func:`p1_flux_finish`."""
+    lib = _capi.load()
+    _dev(kloc, "kloc")
+    _dev(load, "load")
+    ne = kloc.numel()
+    if load.numel() < ne + 1:
+        raise ValueError("load must have at least ne+1 entries")
+    nbytes = lib.lssvr_p1_flux_work_bytes(ne)
+    if work is None or work.numel() * work.element_size() < nbytes:
+        work = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=kloc.device)
+    agg = torch.empty(3, dtype=torch.float64, device=kloc.device)
+    rc = lib.lssvr_p1_flux_aggregate(_ptr(kloc), _ptr(load), ne, int(bool(first_global)), _ptr(work),
+                                     _ptr(agg), _stream(stream))
+    _capi.check(rc, "lssvr_p1_flux_aggregate")
+    return agg, work
+
+
+def p1_flux_finish(kloc, load, work, *, first_global, last_global, prefix=None, grand=None,
+                   u0=0.0, u1=0.0, out=None, stream=None):
+    """Second half of the sharded flux solve: nodal values u[ne+1] of this shard."""
+    lib = _capi.load()
+    ne = kloc.numel()
+    if out is None:
+        out = torch.empty(ne + 1, dtype=torch.float64, device=kloc.device)
+    for t, nm in ((prefix, "prefix"), (grand, "grand")):
+        if t is not None:
+            _dev(t, nm)
+    rc = lib.lssvr_p1_flux_finish(_ptr(kloc), _ptr(load), ne, int(bool(first_global)),
+                                  int(bool(last_global)), _ptr(work), _ptr(prefix), _ptr(grand),
+                                  float(u0), float(u1), _ptr(out), _stream(stream))
+    _capi.check(rc, "lssvr_p1_flux_finish")
+    return out
+
+
 def evaluate(x, W, xq, *, want_elem=True, stream=None):
     """``evaluate_solution`` (Dual.py:176-203) -> (u float64[P], elem int64[P] | None)."""
     lib = _capi.load()

@@ -204,6 +204,25 @@ int lssvr_p1_flux_solve(const double* kloc, const double* load, int64_t ne, doub
                         double* u, void* work, void* stream);
 
 /*
+ * Sharded form of lssvr_p1_flux_solve (one process per GPU, contiguous element shards).
+ * The scan operator is associative, so a shard is summarised by ONE aggregate:
+ *   lssvr_p1_flux_aggregate  -> agg3[3] (device) for the shard's ne elements; `work` (same
+ *                               size rule) keeps the block scan for the second call;
+ *   (caller: all-gather the 24-byte aggregates, combine those of the lower ranks in rank
+ *    order into prefix3 and all of them into grand3 with
+ *    (a1,r1,g1) o (a2,r2,g2) = (a1+a2, r1+r2, g1+g2 + r2*a1) )
+ *   lssvr_p1_flux_finish     -> u[ne+1] of the shard's nodes.
+ * first_global / last_global: the shard holds the mesh's first / last element.  kloc[ne],
+ * load[ne+1] are the shard's slices (load[i] must be complete for i < ne: assemble with one
+ * halo node on the left).  prefix3 / grand3 are DEVICE double[3]; NULL = empty / own total.
+ */
+int lssvr_p1_flux_aggregate(const double* kloc, const double* load, int64_t ne, int first_global,
+                            void* work, double* agg3, void* stream);
+int lssvr_p1_flux_finish(const double* kloc, const double* load, int64_t ne, int first_global,
+                         int last_global, const void* work, const double* prefix3,
+                         const double* grand3, double u0, double u1, double* u, void* stream);
+
+/*
  * lssvr_eval -- `evaluate_solution` (Dual.py:176-203): for each query point the
  * first element j with x[j] <= xq <= x[j+1] (points on an interior node take the
  * LEFT element; below/above the mesh -> element 0 / ne-1, polynomial
