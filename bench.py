@@ -275,6 +275,30 @@ def main():
     k_avg = sum(k_s) / len(k_s)
     k_med = k_s[len(k_s) // 2]
 
+    # the same step on exactly 1e5 elements of [-1, 1] (BASELINE.json's wording of config 2),
+    # where the CPU baseline cannot be timed (SURVEY.md finding 5): shows that the kernel cost
+    # does not depend on the domain
+    narrow = None
+    if world == 1 and args.domain == "wide" and not args.elements:
+        nn = NE_NARROW
+        xn_h = np.arange(nn + 1, dtype=np.float64) * (2.0 / nn) - 1.0
+        xn_h[-1] = 1.0
+        un_h = np.sin(np.pi * xn_h)
+        un_h[0] = un_h[-1] = 0.0
+        xn, un = torch.as_tensor(xn_h, device=dev), torch.as_tensor(un_h, device=dev)
+        pl = ops.StepPlan(xn, un, M, GAMMA, n, global_domain=(-1.0, 1.0))
+        for _ in range(args.warmup):
+            pl.launch(st)
+        torch.cuda.synchronize()
+        tn = time.perf_counter()
+        for _ in range(args.steps):
+            pl.launch(st)
+        torch.cuda.synchronize()
+        tn = time.perf_counter() - tn
+        narrow = {"workload": "%d elements on [-1, 1], same step" % nn,
+                  "value": nn * args.steps / tn, "ms_per_step": tn / args.steps * 1e3,
+                  "fallback_elements": int(pl.status.sum().item())}
+
     # accuracy of what was just timed (reported with every timing), rank 0's
     # shard: sampled elements against the float64 KKT oracle (and the 60-digit minimiser when
     # mpmath is present), and the stitched u(x) against sin(pi x) on a probe grid
@@ -377,6 +401,8 @@ def main():
             out["roofline"]["fp64_fma_probe_tflops"] = round(ops.fp64_probe(8192, 4096, False), 2)
         except Exception as exc:  # pragma: no cover
             out["roofline"]["fp64_fma_probe_tflops"] = "failed: %s" % exc
+        if narrow is not None:
+            out["narrow_domain"] = narrow
         if accuracy is not None:
             out["accuracy"] = accuracy
         if cpu_res is not None:
