@@ -299,6 +299,51 @@ def main():
                   "value": nn * args.steps / tn, "ms_per_step": tn / args.steps * 1e3,
                   "fallback_elements": int(pl.status.sum().item())}
 
+    # the stages around the hot path, each timed on its own (t_global_solve,
+    # t_eval, H2D/D2H are reported separately and never enter `value`)
+    stages = None
+    if rank == 0:
+        def med_us(fn, reps=20):
+            fn()
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(reps):
+                a0 = torch.cuda.Event(enable_timing=True)
+                a1 = torch.cuda.Event(enable_timing=True)
+                a0.record()
+                fn()
+                a1.record()
+                a1.synchronize()
+                ts.append(a0.elapsed_time(a1) * 1e3)
+            return sorted(ts)[len(ts) // 2]
+        try:
+            bl = ops.p1_assemble(x, 2, want_local=True)
+            uq_pts = torch.linspace(float(nodes_h[0]), float(nodes_h[-1]), 2 * ne_loc + 1,
+                                    dtype=torch.float64, device=dev)
+            x_pin = torch.as_tensor(nodes_h).pin_memory()
+            W_pin = torch.empty((ne_loc, M), dtype=torch.float64).pin_memory()
+            stages = {
+                "note": "median of 20, microseconds, event pairs on the launch stream (each includes "
+                        "~4 us of event + dispatch latency); this rank's shard",
+                "p1_assemble_us": med_us(lambda: ops.p1_assemble(x, 2, out=bl)),
+                "dirichlet_solve_bands_us": med_us(lambda: ops.tridiag_dirichlet_solve(bl["diag"], bl["off"], bl["load"])),
+                "dirichlet_solve_flux_us": med_us(lambda: ops.p1_flux_solve(bl["kloc"], bl["load"])),
+                "enhance_us": med_us(lambda: ops.enhance(x, u, M, GAMMA, n, elem_offset=s0, ne_global=ne_glob,
+                                                          global_domain=gd, out=W[:ne_loc], status=status)),
+                "evaluate_2ne_points_us": med_us(lambda: ops.evaluate(x, W[:ne_loc], uq_pts, want_elem=False)),
+                "h2d_nodes_and_values_us": med_us(lambda: (x.copy_(x_pin, non_blocking=True),
+                                                          u.copy_(x_pin, non_blocking=True))),
+                "d2h_coefficients_us": med_us(lambda: W_pin.copy_(W[:ne_loc], non_blocking=True)),
+            }
+            x.copy_(torch.as_tensor(nodes_h))
+            u.copy_(torch.as_tensor(values_h))
+            fused.launch(st)
+            torch.cuda.synchronize()
+            hd = stages["h2d_nodes_and_values_us"] + stages["d2h_coefficients_us"]
+            stages["pcie_inclusive_elements_per_s"] = ne_loc / ((elapsed / args.steps) + hd * 1e-6)
+        except Exception as exc:  # pragma: no cover
+            stages = {"error": repr(exc)}
+
     # accuracy of what was just timed (reported with every timing), rank 0's
     # shard: sampled elements against the float64 KKT oracle (and the 60-digit minimiser when
     # mpmath is present), and the stitched u(x) against sin(pi x) on a probe grid
@@ -401,6 +446,8 @@ def main():
             out["roofline"]["fp64_fma_probe_tflops"] = round(ops.fp64_probe(8192, 4096, False), 2)
         except Exception as exc:  # pragma: no cover
             out["roofline"]["fp64_fma_probe_tflops"] = "failed: %s" % exc
+        if stages is not None:
+            out["stages"] = stages
         if narrow is not None:
             out["narrow_domain"] = narrow
         if accuracy is not None:
