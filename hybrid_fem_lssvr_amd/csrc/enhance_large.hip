@@ -42,11 +42,67 @@ constexpr int kST = 17;                    // tile row stride
 constexpr int kT1 = 16 * kST;              // offset of the second tile
 constexpr int kHalf2 = kBlk + 2 * kLP + kLP;   // block | E (C0_i, C1_i interleaved) | Z
 static_assert(2 * kT1 <= kBlk && 2 * kSL <= kBlk, "tiles / pivot ring alias the operand block");
+
+// The rows use the RESCALED second-derivative family p_m = q_m / c_m (lssvr_device.hpp:
+// p_m = A_m t p_{m-1} - p_{m-2}, one multiply less per term than the q recurrence and a single
+// coefficient table, which the fully unrolled row loops read as s_load batches from the kernel
+// arguments).  Working with p is the diagonal change of variables G' = D^-1 G D^-1, v' = D v,
+// D = diag(c_m): the boundary block becomes C' = C D^-1, the ridge eps D^-2, and the final
+// coefficients w = D^-1 v' -- all per-lane multiplications by kInvScale2[c].
+struct LargeTables {
+  double a2s[kLP];             // A_m = d2_coef(m), m >= 2
+  double sc2[kLP];             // c_m = d2_scale(m)   (variable-coefficient rows need q_m itself)
+  double al1[kLP + 2], be1[kLP + 2];   // L' family (variable-coefficient rows)
+  double sinc[10];             // odd Taylor coefficients of sin, -1/21! .. 1/3! (sin_reduced's)
+};
+
+inline LargeTables make_large_tables() {
+  LargeTables t{};
+  for (int m = 0; m < kLP; ++m) {
+    t.a2s[m] = m >= 2 ? d2_coef(m) : 0.0;
+    t.sc2[m] = d2_scale(m);
+  }
+  for (int m = 1; m < kLP + 2; ++m) {
+    t.al1[m] = (double)(2 * m + 1) / (double)m;
+    t.be1[m] = (double)(m + 1) / (double)m;
+  }
+  const double sinc[10] = {-1.0 / 51090942171709440000.0, 1.0 / 121645100408832000.0,
+                           -1.0 / 355687428096000.0,      1.0 / 1307674368000.0,
+                           -1.0 / 6227020800.0,           1.0 / 39916800.0,
+                           -1.0 / 362880.0,               1.0 / 5040.0,
+                           -1.0 / 120.0,                  1.0 / 6.0};   // sin_reduced's literals
+  for (int i = 0; i < 10; ++i) t.sinc[i] = sinc[i];
+  return t;
+}
+
+// lssvr_device.hpp::sin_reduced with the polynomial coefficients read from the kernel arguments
+// (SGPR operands) instead of 20 VGPRs of hoisted literals -- the kernel runs at 168 registers.
+__device__ __forceinline__ double sin_reduced_tab(double arg, const double* __restrict__ sc) {
+  constexpr double kInvPi = 0.31830988618379067154;
+  constexpr double kPiHi = 3.14159265358979311600e+00;
+  constexpr double kPiLo = 1.22464679914735317723e-16;
+  if (!(fabs(arg) < 3.0e9)) return sin(arg);
+  const double j = rint(arg * kInvPi);
+  double r = fma(-j, kPiHi, arg);
+  r = fma(-j, kPiLo, r);
+  const double z = r * r;
+  double p = sc[0];
+#pragma unroll
+  for (int i = 1; i < 10; ++i) p = fma(p, z, sc[i]);
+  const double s = fma(-(r * z), p, r);
+  const long long ji = (long long)j;
+  return (ji & 1) ? -s : s;
+}
+
+#define LSSVR_IS8(b) 1.0 / d2_scale(b), 1.0 / d2_scale(b + 1), 1.0 / d2_scale(b + 2), 1.0 / d2_scale(b + 3), \
+                     1.0 / d2_scale(b + 4), 1.0 / d2_scale(b + 5), 1.0 / d2_scale(b + 6), 1.0 / d2_scale(b + 7)
+__device__ const double kInvScale2[kLP] = {LSSVR_IS8(0), LSSVR_IS8(8), LSSVR_IS8(16), LSSVR_IS8(24)};
+#undef LSSVR_IS8
 }  // namespace
 
 template <int RHS, bool VC>
 __global__ __launch_bounds__(kWavesPerBlock * 64, 3) void enhance_large_kernel(EnhanceArgs p,
-                                                                               RecTables tb) {
+                                                                               LargeTables tb) {
   __shared__ double2_t lds2[kWavesPerBlock * kHalf2];      // 2 halves x kHalf2 doubles per wave
   double* const lds = reinterpret_cast<double*>(lds2);
   const int lane = threadIdx.x & 63;
@@ -112,6 +168,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 3) void enhance_large_kernel(E
         }
       }
     }
+    const double isc = VC ? 1.0 : kInvScale2[c];   // 1 / c_c of this lane's column
     const double idet = rcp_newton(tbb - ta);
     const double d0 = (tbb * gl - ta * gr) * idet;
     const double d1 = (gr - gl) * idet;
@@ -125,6 +182,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 3) void enhance_large_kernel(E
       } else if (c >= MR) {
         e0c = 0.0;
         e1c = 0.0;
+      } else {
+        e0c *= isc;             // C' = C D^-1
+        e1c *= isc;
       }
       wave_lds_sync();       // previous pair's reads of E / Z are done
       double2_t ev = {e0c, e1c};
@@ -136,13 +196,17 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 3) void enhance_large_kernel(E
     double4_t accB00 = {0, 0, 0, 0}, accB10 = {0, 0, 0, 0}, accB11 = {0, 0, 0, 0};
     const int ar = (lane & 15) * kSB + (lane >> 4);
     for (int k0 = 0; k0 < n; k0 += kCH) {
+      // (an opaque zero in the table index keeps the compiler from hoisting all 31 coefficient
+      // loads out of the chunk loop, where they would occupy 62 SGPRs for the whole kernel)
+      int zi = 0;
+      asm volatile("" : "+s"(zi));
       const int k = k0 + c;
       const bool valid = k < n;
       const double xk = linspace_at(a, b, dm.oldlen, step, valid ? k : 0, n);
       const double tk = dm.off + dm.scl * xk;
       double fk;
       if constexpr (RHS == LSSVR_RHS_SIN) {
-        fk = p.rhs_amp * sin_reduced(p.rhs_omega * xk);
+        fk = p.rhs_amp * sin_reduced_tab(p.rhs_omega * xk, tb.sinc + zi);
       } else {
         fk = valid ? p.rhs_values[e * n + k] : 0.0;
       }
@@ -155,28 +219,36 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 3) void enhance_large_kernel(E
         bk = valid ? p.da_values[e * n + k] / dm.scl : 0.0;
         phi = -fma(bk, d1, fk * inv_scl2) * seed;
       }
-      // recurrence state across the two column halves: q = L''_{j+2}, r = L'_{j+2}
-      double q2 = 0.0, q1 = 0.0, r2 = seed, r1 = 3.0 * tk * seed;
-      auto next_col = [&](int j) -> double {
-        double q;
-        if (j == 0) q = 3.0 * seed;
-        else if (j == 1) q = 15.0 * tk * seed;
-        else q = fma(tb.al2[j] * tk, q1, -(tb.be2[j] * q2));
-        q2 = q1;
-        q1 = q;
-        double val = q;
+      // Recurrence state across the two column halves: p = L''_{j+2} / c_j, r = L'_{j+2}.
+      // Columns j >= MR (padding, M < 33) carry on with the recurrence: their Gram rows and
+      // columns never meet a pivot, a live column's solution or the rhs row (elimination
+      // stops at MR, E is zero there), so they need no masking.
+      double p2 = 0.0, p1 = 0.0, r2 = seed, r1 = 3.0 * tk * seed;
+      const double* const a2s = tb.a2s + zi;
+      const double* const sc2 = tb.sc2 + zi;
+      const double* const al1 = tb.al1 + zi;
+      const double* const be1 = tb.be1 + zi;
+      auto next_col = [&](const int j) -> double {
+        double pj;
+        if (j == 0) pj = 3.0 * seed;
+        else if (j == 1) pj = 15.0 * tk * seed;
+        else pj = fma(a2s[j] * tk, p1, -p2);
+        p2 = p1;
+        p1 = pj;
         if constexpr (VC) {
-          // rho_j = a q_j + b (L'_{j+2} - C1_j)
-          val = fma(ak, q, bk * (r1 - E[2 * j + 1]) * seed);
-          const double rn = fma(tb.al1[j + 2] * tk, r1, -(tb.be1[j + 2] * r2));
+          // rho_j = a q_j + b (L'_{j+2} - C1_j),  q_j = c_j p_j
+          const double val = fma(ak, pj * sc2[j], bk * (r1 - E[2 * j + 1]) * seed);
+          const double rn = fma(al1[j + 2] * tk, r1, -(be1[j + 2] * r2));
           r2 = r1;
           r1 = rn;
+          return val;
+        } else {
+          return pj;
         }
-        return (j < MR) ? val : 0.0;
       };
 
       wave_lds_sync();   // the previous chunk's operand reads (and the E writes) are done
-#pragma nounroll
+#pragma unroll
       for (int j = 0; j < 16; ++j) Bf[j * kSB + c] = next_col(j);
       wave_lds_sync();
       double a0[kCH / 4], b0[kCH / 4];
@@ -186,7 +258,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 3) void enhance_large_kernel(E
         b0[s] = BfB[ar + 4 * s];
       }
       wave_lds_sync();
-#pragma nounroll
+#pragma unroll
       for (int j = 16; j < kRhsRow; ++j) Bf[(j - 16) * kSB + c] = next_col(j);
       Bf[(kRhsRow - 16) * kSB + c] = phi;        // rhs always rides in the last column
       wave_lds_sync();
@@ -218,7 +290,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 3) void enhance_large_kernel(E
     }
     wave_lds_sync();
     // + eps on the diagonal of the MR x MR block (lane c owns G[c][c] of its element)
-    if (c < 16 && c < MR) Bf[c * kST + c] += eps;
+    const double epsd = eps * isc * isc;           // eps D^-2
+    if (c < 16 && c < MR) Bf[c * kST + c] += epsd;
     wave_lds_sync();
     // S = G + eps (I + C^T C): lane c takes column c.  Rows 0..15: G[i][c] is tile (0,0)
     // [c][i] (symmetric) for c < 16 and tile (1,0) [c-16][i] for c >= 16.
@@ -244,7 +317,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 3) void enhance_large_kernel(E
       BfB[row * kST + tcol] = accB11[q];
     }
     wave_lds_sync();
-    if (c >= 16 && c < MR) Bf[(c - 16) * kST + (c - 16)] += eps;
+    if (c >= 16 && c < MR) Bf[(c - 16) * kST + (c - 16)] += epsd;
     wave_lds_sync();
     {
       const int base1 = (c < 16) ? kT1 + c : c - 16;
@@ -268,7 +341,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 3) void enhance_large_kernel(E
     // ---- store: lane c -> W[e][c+2]; lane 0 also writes w0, w1 -----------------------------
     if (live) {
       double* const Wrow = p.W + e * M;
-      if (c < MR) Wrow[c + 2] = ok ? v : 0.0;
+      if (c < MR) Wrow[c + 2] = ok ? v * isc : 0.0;    // w = D^-1 v'
       if (c == 0) {
         Wrow[0] = ok ? w0 : 0.5 * (gl + gr);
         Wrow[1] = ok ? w1 : 0.5 * (gr - gl);
@@ -281,7 +354,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 3) void enhance_large_kernel(E
 
 hipError_t enhance_large(const EnhanceArgs& a, hipStream_t s, const LaunchOpts* o) {
   if (a.M - 2 + 1 > kLP) return hipErrorInvalidValue;
-  static const RecTables tables = make_rec_tables();
+  static const LargeTables tables = make_large_tables();
   const int64_t npair = (a.ne + 1) / 2;
   const int64_t blocks = (npair + kWavesPerBlock - 1) / kWavesPerBlock;
   if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;

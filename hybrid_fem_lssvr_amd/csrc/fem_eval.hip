@@ -266,6 +266,34 @@ __global__ __launch_bounds__(kBlock) void fp64_mfma_probe_kernel(double* out, in
   out[tid] = (c0[0] + c1[1]) + (c2[2] + c3[3]);
 }
 
+// Do the f64 MFMA and the FP64 vector FMA overlap on one SIMD?  Even workgroups run the MFMA
+// loop, odd ones the FMA loop with 8x the iterations (same pipe time each); every SIMD hosts
+// both kinds.  Overlapping pipes finish in ~max of the two single-kind runs, a shared pipe
+// in ~their sum (scripts/maskprobe.py prints the three durations).
+__global__ __launch_bounds__(kBlock) void fp64_mixed_probe_kernel(double* out, int iters) {
+  const int tid = blockIdx.x * kBlock + threadIdx.x;
+  if (blockIdx.x & 1) {
+    double a0 = 1.0 + tid * 1e-9, a1 = a0 + 0.1, a2 = a0 + 0.2, a3 = a0 + 0.3;
+    double a4 = a0 + 0.4, a5 = a0 + 0.5, a6 = a0 + 0.6, a7 = a0 + 0.7;
+    const double m = 0.999999, c = 1e-7;
+    for (int i = 0; i < 8 * iters; ++i) {
+      a0 = fma(a0, m, c); a1 = fma(a1, m, c); a2 = fma(a2, m, c); a3 = fma(a3, m, c);
+      a4 = fma(a4, m, c); a5 = fma(a5, m, c); a6 = fma(a6, m, c); a7 = fma(a7, m, c);
+    }
+    out[tid] = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+  } else {
+    double4_t c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+    const double a = 1.0 + (tid & 63) * 1e-3, b = 1.0 - (tid & 63) * 1e-3;
+    for (int i = 0; i < iters; ++i) {
+      c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c1, 0, 0, 0);
+      c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c2, 0, 0, 0);
+      c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c3, 0, 0, 0);
+    }
+    out[tid] = (c0[0] + c1[1]) + (c2[2] + c3[3]);
+  }
+}
+
 // 8-byte-per-lane streaming copy with a known byte count: calibrates rocprofv3's
 // FETCH_SIZE / WRITE_SIZE for the access width the enhancement kernels use.
 __global__ __launch_bounds__(kBlock) void stream_copy_probe_kernel(const double* __restrict__ src,
@@ -284,7 +312,9 @@ hipError_t stream_probe(const double* src, double* dst, int64_t n, hipStream_t s
 }
 
 hipError_t fp64_probe(double* out, int blocks, int iters, int use_mfma, hipStream_t s) {
-  if (use_mfma >= 100)
+  if (use_mfma == 2)
+    hipLaunchKernelGGL(fp64_mixed_probe_kernel, dim3(blocks), dim3(kBlock), 0, s, out, iters);
+  else if (use_mfma >= 100)
     hipLaunchKernelGGL(fp64_fma_masked_probe_kernel, dim3(blocks), dim3(kBlock), 0, s, out, iters,
                        use_mfma - 100);
   else if (use_mfma)
