@@ -103,33 +103,37 @@ __device__ __forceinline__ void enhance_small_body(const EnhanceArgs& p, const u
       //   sin(arg_k) = s~ + c~ delta,  delta = (arg_k - th0) - k dth   (|delta| ~ |omega x| eps).
       // delta^2/2 and the rotation's rounding (<= ~n eps) are far below the 1e-13 parity bar;
       // a wave with any |delta| > 1e-7 (|omega x| > ~1e8) takes the per-point sin instead.
-      double rs = 0.0, rc = 1.0, sd = 0.0, cd = 1.0, th0 = 0.0, dth = 0.0;
+      // The rotation is linear, so the pair is carried pre-multiplied by kappa = -amp / scl^2:
+      // phi_k = -f(x_k) / scl^2 comes out of the correction FMA directly.
+      double rs = 0.0, rc = 1.0, sd = 0.0, cd = 1.0, th0 = 0.0, dth = 0.0, kappa = 0.0;
       if constexpr (RHS == LSSVR_RHS_SIN) {
         th0 = p.rhs_omega * a;
         dth = p.rhs_omega * step;
         sincos_reduced(th0, rs, rc);
         sincos_reduced(dth, sd, cd);
+        kappa = -(p.rhs_amp * inv_scl2);
+        rs *= kappa;
+        rc *= kappa;
       }
       for (int k = 0; k < n; ++k) {
         const double xk = linspace_at(a, b, dm.oldlen, step, k, n);
         const double tk = dm.off + dm.scl * xk;
-        double fk;
+        double fk = 0.0, phi;
         if constexpr (RHS == LSSVR_RHS_SIN) {
           const double arg = p.rhs_omega * xk;
           const double delta = fma(-(double)k, dth, arg - th0);
-          double sk = fma(rc, delta, rs);
-          if (__any(!(fabs(delta) < 1.0e-7))) sk = sin_reduced(arg);
-          fk = p.rhs_amp * sk;
+          phi = fma(rc, delta, rs);
+          if (__any(!(fabs(delta) < 1.0e-7))) phi = kappa * sin_reduced(arg);
           const double rs_next = fma(rs, cd, rc * sd);
           rc = fma(rc, cd, -(rs * sd));
           rs = rs_next;
         } else {
           fk = p.rhs_values[e * n + k];
+          phi = -(fk * inv_scl2);
         }
         double rho[MR];
         if constexpr (VC) legendre_d2<MR>(tk, rho);
         else legendre_d2_scaled<MR>(tk, rho);
-        double phi = -(fk * inv_scl2);
         if constexpr (VC) {
           const double ak = p.a_values[e * n + k];
           const double bk = p.da_values[e * n + k] / dm.scl;
@@ -142,10 +146,14 @@ __device__ __forceinline__ void enhance_small_body(const EnhanceArgs& p, const u
 #pragma unroll
         for (int i = 0; i < MR; ++i) {
 #pragma unroll
-          for (int j = 0; j <= i; ++j) G[tri(i, j)] = fma(rho[i], rho[j], G[tri(i, j)]);
+          for (int j = 0; j <= i; ++j) {
+            if (!VC && i == 0) continue;       // rho_0 = 3 for every point: G_00 = 9 n, set below
+            G[tri(i, j)] = fma(rho[i], rho[j], G[tri(i, j)]);
+          }
           rv[i] = fma(rho[i], phi, rv[i]);
         }
       }
+      if constexpr (!VC) G[0] = 9.0 * (double)n;
 
       if constexpr (!VC) boundary_rows();
       // --- S = G + eps (I + C^T C),  rhs = r + eps C^T d --------------------------

@@ -174,7 +174,9 @@ __device__ __forceinline__ double ldlt_solve_frozen(double (&col)[kLP], double* 
   asm volatile("" : "+v"(cc));     // opaque copies: keep the 31 lane masks / uniform
   int ns = nsys;                   // conditions from being hoisted out of the element loop
   asm volatile("" : "+s"(ns));
-  double dmin = 1.0, dmine = 1.0;
+  // pivot checks: d_j <= -0 sets the sign bit of the OR of the high words; a zero or non-finite
+  // pivot makes 1/d_j inf / NaN and reaches the solution, where the caller tests finiteness
+  int signs = 0;
   R[c] = col[0];
   wave_lds_sync();
 #pragma unroll
@@ -183,13 +185,14 @@ __device__ __forceinline__ double ldlt_solve_frozen(double (&col)[kLP], double* 
       const double* const Rj = R + (j & 1) * kSL;
       double* const Rn = R + ((j + 1) & 1) * kSL;
       const double dj = Rj[j];
-      dmin = fmin(dmin, dj);
-      if (cc == j) dmine = dj;
+      signs |= __double2hiint(dj);
       const double rinv = rcp_newton(dj);
       if (cc > j) {
         const double tcj = col[j] * rinv;                       // a_jc / d_j
         // row j+1 of every live column first, then publish it (one step of software
-        // pipelining: its LDS round trip overlaps the remaining updates of step j)
+        // pipelining: its LDS round trip overlaps the remaining updates of step j).
+        // Only live lanes publish: the last thing lane c ever writes is therefore its own
+        // pivot d_c = a_cc (row c, step c-1), which stays at slot (c & 1), position c.
         col[j + 1] = fma(-Rj[j + 1], tcj, col[j + 1]);
         if (j + 1 < kLP - 1) Rn[c] = col[j + 1];
         if ((j + 2) & 1) col[j + 2] = fma(-Rj[j + 2], tcj, col[j + 2]);
@@ -203,15 +206,16 @@ __device__ __forceinline__ double ldlt_solve_frozen(double (&col)[kLP], double* 
       wave_lds_sync();
     }
   }
-  pivots_ok = dmin > 0.0;
+  pivots_ok = signs >= 0;
   // backward substitution L^T z = D^-1 y out of the frozen columns:
   //   z_t = (a_{rhs,t} - sum_{i>t} a_it z_i) / d_t
   double Y = col[kRhsRow];
-  double rinv = rcp_newton(dmine);
+  double rinv = rcp_newton(R[(c & 1) * kSL + c]);
   if (c >= nsys) {
     Y = 0.0;
     rinv = 0.0;
   }
+  wave_lds_sync();
   asm volatile("" : "+s"(ns));
 #pragma unroll
   for (int i = kLP - 2; i >= 1; --i) {
