@@ -8,14 +8,14 @@
 //
 //   [G r; r^T *] = sum_k [rho;phi]_k [rho;phi]_k^T            (32 x 32, contraction over k)
 //
-// is three 16x16 tiles of v_mfma_f64_16x16x4_f64 per 4 collocation points.
+// is three 16x16 tiles, each computed as 4x4 blocks by v_mfma_f64_4x4x4_4b_f64 (see below).
 // Lane (c = lane&31, h = lane>>5) works for element 2*pair + h:
 //   1. as collocation point c of a 32-point chunk: abscissa, f, Gegenbauer recurrence.
 //      The Vandermonde block goes through LDS in TWO HALVES of 16 columns (column stride 34
 //      doubles: conflict-free for the point-major writes and for the operand reads): columns
 //      0..15 are written, every lane picks up its 8 MFMA operands of them, then the recurrence
 //      carries on (two registers of state) and columns 16..31 take the same 4.3 KB;
-//   2. 8 k-steps x 3 MFMAs per chunk and element, operands and accumulators in registers;
+//   2. 8 k-steps x 10 block MFMAs per chunk and element, operands and accumulators in registers;
 //   3. accumulators -> LDS in two stages (tiles (0,0)+(1,0), then (1,1) in the place of (0,0))
 //      -> lane c owns column c of S (32 rows in registers); the right-hand side rides along as
 //      row/column 31, so forward substitution is free;
@@ -92,6 +92,54 @@ __device__ __forceinline__ double sin_reduced_tab(double arg, const double* __re
   const double s = fma(-(r * z), p, r);
   const long long ji = (long long)j;
   return (ji & 1) ? -s : s;
+}
+
+
+// ---- f64 MFMA in 4x4x4 blocks ------------------------------------------------------------
+// Measured on gfx950 (variants/mfma_probe.cpp): v_mfma_f64_4x4x4_4b_f64 (four 4x4x4
+// blocks, 256 FMAs) takes 8.2 ns per SIMD, v_mfma_f64_16x16x4_f64 (1024 FMAs) 42 ns -- 28 % more
+// per FMA -- and both share the FP64 vector pipe.  Operand layout (probed with one-hot inputs):
+//   A: lane 16 k + 4 blk + i = A_blk[i][k]   B: lane 16 k + 4 blk + j = B_blk[k][j]
+//   D: lane 16 i + 4 blk + j = D_blk[i][j]
+// A 16 x 16 tile of the Gram matrix is 4 x 4 blocks.  With A = the tile's row operand in the
+// layout above (block row blk = rows 4 blk .. 4 blk + 3) and B = the column operand ROTATED by r
+// quads inside every 16-lane row (DPP row_ror, two v_mov_dpp per double, no LDS), one
+// instruction yields the four blocks (blk, (blk + r) & 3).  A symmetric tile needs r = 0, 1, 2
+// (10 distinct blocks incl. mirrors), the off-diagonal tile r = 0 .. 3: 10 instructions per
+// 4 collocation points and element instead of 3 of the 16x16x4 kind -- 82 ns instead of 126.
+template <int R>
+__device__ __forceinline__ double row_rot_quads(double v) {
+  // out[m] = in[(m + 4 R) & 15] inside every row of 16 lanes: row_ror by 16 - 4 R
+  constexpr int ctrl = 0x120 + ((16 - 4 * R) & 15);
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const int lo = __builtin_amdgcn_mov_dpp((int)(unsigned)u, ctrl, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_mov_dpp((int)(unsigned)(u >> 32), ctrl, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+
+#define LSSVR_MFMA4(acc, av, bv) acc = __builtin_amdgcn_mfma_f64_4x4x4f64(av, bv, acc, 0, 0, 0)
+
+// the ten accumulators of one element: sym[0..2] tile (0,0) r = 0,1,2; off[0..3] tile (1,0);
+// low[0..2] tile (1,1)
+struct GramAcc {
+  double sym[3], off[4], low[3];
+};
+
+__device__ __forceinline__ void gram_step(GramAcc& g, double v0, double v1, bool need11) {
+  const double v0r1 = row_rot_quads<1>(v0), v0r2 = row_rot_quads<2>(v0), v0r3 = row_rot_quads<3>(v0);
+  LSSVR_MFMA4(g.sym[0], v0, v0);
+  LSSVR_MFMA4(g.sym[1], v0, v0r1);
+  LSSVR_MFMA4(g.sym[2], v0, v0r2);
+  LSSVR_MFMA4(g.off[0], v1, v0);
+  LSSVR_MFMA4(g.off[1], v1, v0r1);
+  LSSVR_MFMA4(g.off[2], v1, v0r2);
+  LSSVR_MFMA4(g.off[3], v1, v0r3);
+  if (need11) {
+    const double v1r1 = row_rot_quads<1>(v1), v1r2 = row_rot_quads<2>(v1);
+    LSSVR_MFMA4(g.low[0], v1, v1);
+    LSSVR_MFMA4(g.low[1], v1, v1r1);
+    LSSVR_MFMA4(g.low[2], v1, v1r2);
+  }
 }
 
 #define LSSVR_IS8(b) 1.0 / d2_scale(b), 1.0 / d2_scale(b + 1), 1.0 / d2_scale(b + 2), 1.0 / d2_scale(b + 3), \
@@ -192,8 +240,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 3) void enhance_large_kernel(E
     }
 
     // ---- Gram contraction on the matrix cores ----------------------------------------
-    double4_t accA00 = {0, 0, 0, 0}, accA10 = {0, 0, 0, 0}, accA11 = {0, 0, 0, 0};
-    double4_t accB00 = {0, 0, 0, 0}, accB10 = {0, 0, 0, 0}, accB11 = {0, 0, 0, 0};
+    GramAcc gA = {}, gB = {};
     const int ar = (lane & 15) * kSB + (lane >> 4);
     for (int k0 = 0; k0 < n; k0 += kCH) {
       // (an opaque zero in the table index keeps the compiler from hoisting all 31 coefficient
@@ -266,27 +313,30 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 3) void enhance_large_kernel(E
       for (int s = 0; s < kCH / 4; ++s) {
         const double a1 = BfA[ar + 4 * s];
         const double b1 = BfB[ar + 4 * s];
-        accA00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[s], a0[s], accA00, 0, 0, 0);
-        accB00 = __builtin_amdgcn_mfma_f64_16x16x4f64(b0[s], b0[s], accB00, 0, 0, 0);
-        accA10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a0[s], accA10, 0, 0, 0);
-        accB10 = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, b0[s], accB10, 0, 0, 0);
-        if (need11) {
-          accA11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, accA11, 0, 0, 0);
-          accB11 = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, b1, accB11, 0, 0, 0);
-        }
+        gram_step(gA, a0[s], a1, need11);
+        gram_step(gB, b0[s], b1, need11);
       }
     }
 
     // ---- accumulators -> columns.  Stage 1: tiles (0,0) and (1,0), [row][col], stride 17 ----
     wave_lds_sync();
-    const int tcol = lane & 15, trb = lane >> 4;
+    // D layout: lane 16 i + 4 blk + j holds element [4 blk + i][4 ((blk + r) & 3) + j] of its tile
+    const int ti = lane >> 4, tblk = (lane >> 2) & 3, tj = lane & 3;
+    const int trow = 4 * tblk + ti;
+    int tcol[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int row = trb + 4 * q;
-      BfA[row * kST + tcol] = accA00[q];
-      BfA[kT1 + row * kST + tcol] = accA10[q];
-      BfB[row * kST + tcol] = accB00[q];
-      BfB[kT1 + row * kST + tcol] = accB10[q];
+    for (int r = 0; r < 4; ++r) tcol[r] = 4 * ((tblk + r) & 3) + tj;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      BfA[trow * kST + tcol[r]] = gA.sym[r];
+      BfB[trow * kST + tcol[r]] = gB.sym[r];
+    }
+    BfA[tcol[1] * kST + trow] = gA.sym[1];        // mirrors of the r = 1 blocks
+    BfB[tcol[1] * kST + trow] = gB.sym[1];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      BfA[kT1 + trow * kST + tcol[r]] = gA.off[r];
+      BfB[kT1 + trow * kST + tcol[r]] = gB.off[r];
     }
     wave_lds_sync();
     // + eps on the diagonal of the MR x MR block (lane c owns G[c][c] of its element)
@@ -311,11 +361,12 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 3) void enhance_large_kernel(E
     // for c < 16, tile (1,1) [i-16][c-16] for c >= 16.
     wave_lds_sync();
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int row = trb + 4 * q;
-      BfA[row * kST + tcol] = accA11[q];
-      BfB[row * kST + tcol] = accB11[q];
+    for (int r = 0; r < 3; ++r) {
+      BfA[trow * kST + tcol[r]] = gA.low[r];
+      BfB[trow * kST + tcol[r]] = gB.low[r];
     }
+    BfA[tcol[1] * kST + trow] = gA.low[1];
+    BfB[tcol[1] * kST + trow] = gB.low[1];
     wave_lds_sync();
     if (c >= 16 && c < MR) Bf[(c - 16) * kST + (c - 16)] += epsd;
     wave_lds_sync();
@@ -331,12 +382,17 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 3) void enhance_large_kernel(E
     wave_lds_sync();    // G is dead from here on; the pivot-row ring reuses the region
 
     // ---- LDL^T factor + solve of the MR x MR block, rhs carried as row/column 31 ------------
-    bool piv_ok;
-    const double v = ldlt_solve_frozen(col, Bf, Z, c, MR, piv_ok);
+#ifdef LSSVR_LARGE_LDS_FACTOR
+    bool lane_ok;
+    const double v = ldlt_solve_frozen(col, Bf, Z, c, MR, lane_ok);
+#else
+    bool lane_ok;
+    const double v = ldlt_solve_dpp(col, Z, c, MR, lane_ok);
+#endif
     const double w0 = d0 - half_sum(((c < MR) ? e0c : 0.0) * v);
     const double w1 = d1 - half_sum(((c < MR) ? e1c : 0.0) * v);
-    const double bad = half_sum((fabs(v) < 1.0e300) ? 0.0 : 1.0);
-    const bool ok = piv_ok && (bad == 0.0) && (fabs(w0) < 1e300) && (fabs(w1) < 1e300);
+    const double bad = half_sum((lane_ok && fabs(v) < 1.0e300) ? 0.0 : 1.0);
+    const bool ok = (bad == 0.0) && (fabs(w0) < 1e300) && (fabs(w1) < 1e300);
 
     // ---- store: lane c -> W[e][c+2]; lane 0 also writes w0, w1 -----------------------------
     if (live) {

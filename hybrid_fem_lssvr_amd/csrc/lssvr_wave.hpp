@@ -3,6 +3,7 @@
 // 32 x 32 symmetric system held one column per lane (two systems per wave, one per
 // 32-lane half).
 #pragma once
+#include <type_traits>
 #include "lssvr_device.hpp"
 #include "lssvr_kernels.hpp"
 
@@ -211,6 +212,90 @@ __device__ __forceinline__ double ldlt_solve_frozen(double (&col)[kLP], double* 
   //   z_t = (a_{rhs,t} - sum_{i>t} a_it z_i) / d_t
   double Y = col[kRhsRow];
   double rinv = rcp_newton(R[(c & 1) * kSL + c]);
+  if (c >= nsys) {
+    Y = 0.0;
+    rinv = 0.0;
+  }
+  wave_lds_sync();
+  asm volatile("" : "+s"(ns));
+#pragma unroll
+  for (int i = kLP - 2; i >= 1; --i) {
+    if (i < ns) {
+      Z[c] = Y * rinv;
+      wave_lds_sync();
+      const double zi = Z[i];
+      if (cc < i) Y = fma(-col[i], zi, Y);
+    }
+  }
+  return (c < nsys) ? Y * rinv : 0.0;
+}
+
+
+// ---------------------------------------------------------------------------
+// The same elimination with NO LDS AT ALL in the factorisation: the pivot row is broadcast
+// by DPP.  gfx90a+ allows DPP on the 64-bit VOP2 v_fmac_f64 for row_newbcast (lane n of each
+// 16-lane row feeds the whole row), so  a_ic -= a_ji t_c  is ONE instruction
+//     v_fmac_f64_dpp col[i], P, ntc  row_newbcast:(i & 15)
+// with P = the register col[j] seen across lanes (lane i holds a_ji).  A system spans two
+// rows (32 lanes); gfx950's v_permlane16_swap turns two copies of P into t0 = the even row's
+// data in both rows and t1 = the odd row's, so every lane finds a_ji in its own row.  The
+// pivot reciprocal is taken element-wise on the copy whose lane (j & 15) holds d_j and
+// reaches every lane through the same broadcast.  Everything runs with the full EXEC mask
+// (a DPP source lane must be active); a column freezes because its multiplier is zeroed
+// from its own pivot step on.  Versus the LDS version (ldlt_solve_frozen): 250 ds_read_b128
+// + 62 ds_read/ds_write_b64 fewer per element pair, 7 more VALU instructions per step.
+// ---------------------------------------------------------------------------
+template <int I>
+__device__ __forceinline__ void fmac_rowbcast(double& acc, double rowdata, double mul) {
+  asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+      : "+v"(acc)
+      : "v"(rowdata), "v"(mul), "n"(I));
+}
+
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+
+// Returns z_c; lane_ok = this lane's own pivot was positive (lanes >= nsys: true).
+__device__ __forceinline__ double ldlt_solve_dpp(double (&col)[kLP], double* __restrict__ Z,
+                                                 int c, int nsys, bool& lane_ok) {
+  int cc = c;
+  asm volatile("" : "+v"(cc));
+  int ns = nsys;
+  asm volatile("" : "+s"(ns));
+  double nrinv_own = -1.0;          // -1/d_c of this lane's own pivot, latched at step c
+  static_for<0, kLP - 1>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    if (j < ns) {
+      const unsigned long long pu = __builtin_bit_cast(unsigned long long, col[j]);
+      const unsigned plo = (unsigned)pu, phi = (unsigned)(pu >> 32);
+      const auto slo = __builtin_amdgcn_permlane16_swap(plo, plo, false, false);
+      const auto shi = __builtin_amdgcn_permlane16_swap(phi, phi, false, false);
+      double t0 = __builtin_bit_cast(double, ((unsigned long long)(unsigned)shi[0] << 32) | (unsigned)slo[0]);
+      double t1 = __builtin_bit_cast(double, ((unsigned long long)(unsigned)shi[1] << 32) | (unsigned)slo[1]);
+      double nrinv = -rcp_newton(j < 16 ? t0 : t1);        // lane (j & 15) of each row: -1/d_j
+      if (cc == j) nrinv_own = nrinv;
+      // DPP reads of a VGPR need two wait states after the VALU write (the compiler cannot
+      // see the DPP inside the asm statements)
+      asm volatile("s_nop 1" : "+v"(t0), "+v"(t1), "+v"(nrinv));
+      double ntc = 0.0;
+      fmac_rowbcast<(j & 15)>(ntc, nrinv, col[j]);          // -a_jc / d_j on every lane
+      if (!(cc > j)) ntc = 0.0;                             // frozen columns stay as they are
+      asm volatile("s_nop 0" : "+v"(ntc));
+      static_for<j + 1, kLP>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        fmac_rowbcast<(i & 15)>(col[i], i < 16 ? t0 : t1, ntc);
+      });
+    }
+  });
+  lane_ok = (nrinv_own < 0.0) || (c >= nsys);
+  // backward substitution L^T z = D^-1 y out of the frozen columns (z_i through 32 doubles of LDS)
+  double Y = col[kRhsRow];
+  double rinv = -nrinv_own;
   if (c >= nsys) {
     Y = 0.0;
     rinv = 0.0;
