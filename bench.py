@@ -218,52 +218,112 @@ def main():
     # a side stream (double-buffered, equal shards: the gather lands directly in Wg, no copies)
     stitch = None
     if gather:
-        Wb = [W[:ne_loc], torch.empty((ne_loc, M), dtype=torch.float64, device=dev)]
-        Wgb = [Wg, torch.empty_like(Wg)]
-        plans = [ops.StepPlan(x, u, M, GAMMA, n, elem_offset=s0, ne_global=ne_glob, global_domain=gd,
-                              bands=bands, out=Wb[k], status=status) for k in range(2)]
-        comm = torch.cuda.Stream(device=dev)
-        main = torch.cuda.current_stream(dev)
-        done = [None, None]
+        try:
+            Wb = [W[:ne_loc], torch.empty((ne_loc, M), dtype=torch.float64, device=dev)]
+            Wgb = [Wg, torch.empty_like(Wg)]
+            plans = [ops.StepPlan(x, u, M, GAMMA, n, elem_offset=s0, ne_global=ne_glob, global_domain=gd,
+                                  bands=bands, out=Wb[k], status=status) for k in range(2)]
+            comm = torch.cuda.Stream(device=dev)
+            main = torch.cuda.current_stream(dev)
+            done = [None, None]
 
-        def stitched_step(i):
-            k = i & 1
-            if done[k] is not None:
-                main.wait_event(done[k])            # the gather that read W[k] has finished
-            plans[k].launch(main.cuda_stream)
-            ready = torch.cuda.Event()
-            ready.record(main)
-            comm.wait_event(ready)
-            with torch.cuda.stream(comm):
-                dist.all_gather_into_tensor(Wgb[k].view(-1), Wb[k].view(-1))
-                done[k] = torch.cuda.Event()
-                done[k].record(comm)
+            def stitched_step(i):
+                k = i & 1
+                if done[k] is not None:
+                    main.wait_event(done[k])            # the gather that read W[k] has finished
+                plans[k].launch(main.cuda_stream)
+                ready = torch.cuda.Event()
+                ready.record(main)
+                comm.wait_event(ready)
+                with torch.cuda.stream(comm):
+                    dist.all_gather_into_tensor(Wgb[k].view(-1), Wb[k].view(-1))
+                    done[k] = torch.cuda.Event()
+                    done[k].record(comm)
 
-        for i in range(max(args.warmup, 2)):
-            stitched_step(i)
-        torch.cuda.synchronize()
-        barrier()
-        t1 = time.perf_counter()
-        for i in range(args.steps):
-            stitched_step(i)
-        torch.cuda.synchronize()
-        barrier()
-        torch.cuda.synchronize()
-        el2 = time.perf_counter() - t1
-        t = torch.tensor([el2], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el2 = float(t.item())
-        # correctness of the stitch: rank r's block of the gathered array equals what rank r holds
-        mine = Wgb[(args.steps - 1) & 1][s0:s1]
-        same = bool(torch.equal(mine, Wb[(args.steps - 1) & 1]))
-        stitch = {
-            "what": "RCCL all-gather of W over xGMI, overlapped with the next step's kernel",
-            "value_with_allgather": ne_glob * args.steps / el2,
-            "ms_per_step": el2 / args.steps * 1e3,
-            "bytes_received_per_rank_per_step": (world - 1) * ne_loc * M * 8,
-            "recv_GBps_per_rank": (world - 1) * ne_loc * M * 8 / (el2 / args.steps) / 1e9,
-            "own_block_intact": same,
-        }
+            for i in range(max(args.warmup, 2)):
+                stitched_step(i)
+            torch.cuda.synchronize()
+            barrier()
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                stitched_step(i)
+            torch.cuda.synchronize()
+            barrier()
+            torch.cuda.synchronize()
+            el2 = time.perf_counter() - t1
+            t = torch.tensor([el2], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el2 = float(t.item())
+            # correctness of the stitch: rank r's block of the gathered array equals what rank r holds
+            mine = Wgb[(args.steps - 1) & 1][s0:s1]
+            same = bool(torch.equal(mine, Wb[(args.steps - 1) & 1]))
+            stitch = {
+                "what": "RCCL all-gather of W over xGMI, overlapped with the next step's kernel",
+                "value_with_allgather": ne_glob * args.steps / el2,
+                "ms_per_step": el2 / args.steps * 1e3,
+                "bytes_received_per_rank_per_step": (world - 1) * ne_loc * M * 8,
+                "recv_GBps_per_rank": (world - 1) * ne_loc * M * 8 / (el2 / args.steps) / 1e9,
+                "own_block_intact": same,
+            }
+        except Exception as exc:  # pragma: no cover
+            stitch = {"error": repr(exc)}
+
+    # the same stitch for the sampled solution instead of the coefficients (north_star: "all-gather
+    # ... to stitch the global enhanced solution vector"): every rank evaluates its own shard at
+    # two interior points per element (lssvr_eval, rank-local) and gathers 16 B per element
+    # instead of 72; third timed region, same K steps, same double buffering
+    stitch_u = None
+    if gather:
+        try:
+            h_el = x[1:] - x[:-1]
+            xq = torch.stack([x[:-1] + 0.25 * h_el, x[:-1] + 0.75 * h_el], dim=1).reshape(-1).contiguous()
+            P_loc = xq.numel()
+            ub = [torch.empty(P_loc, dtype=torch.float64, device=dev) for _ in range(2)]
+            ug = [torch.empty(P_loc * world, dtype=torch.float64, device=dev) for _ in range(2)]
+            done_u = [None, None]
+
+            def stitched_u_step(i):
+                k = i & 1
+                if done_u[k] is not None:
+                    main.wait_event(done_u[k])
+                plans[k].launch(main.cuda_stream)
+                ops.evaluate(x, Wb[k], xq, want_elem=False, out=ub[k], stream=main.cuda_stream)
+                ready = torch.cuda.Event()
+                ready.record(main)
+                comm.wait_event(ready)
+                with torch.cuda.stream(comm):
+                    dist.all_gather_into_tensor(ug[k], ub[k])
+                    done_u[k] = torch.cuda.Event()
+                    done_u[k].record(comm)
+
+            for i in range(max(args.warmup, 2)):
+                stitched_u_step(i)
+            torch.cuda.synchronize()
+            barrier()
+            t2 = time.perf_counter()
+            for i in range(args.steps):
+                stitched_u_step(i)
+            torch.cuda.synchronize()
+            barrier()
+            torch.cuda.synchronize()
+            el3 = time.perf_counter() - t2
+            t = torch.tensor([el3], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el3 = float(t.item())
+            kk = (args.steps - 1) & 1
+            own = bool(torch.equal(ug[kk][rank * P_loc:(rank + 1) * P_loc], ub[kk]))
+            stitch_u = {
+                "what": "rank-local lssvr_eval at 2 interior points per element + RCCL all-gather of u "
+                        "(16 B per element), overlapped with the next step's kernels",
+                "value_with_allgather": ne_glob * args.steps / el3,
+                "ms_per_step": el3 / args.steps * 1e3,
+                "points_total": P_loc * world,
+                "bytes_received_per_rank_per_step": (world - 1) * P_loc * 8,
+                "recv_GBps_per_rank": (world - 1) * P_loc * 8 / (el3 / args.steps) / 1e9,
+                "own_block_intact": own,
+            }
+        except Exception as exc:  # pragma: no cover
+            stitch_u = {"error": repr(exc)}
 
     # dominant kernel (the per-element enhancement): launch duration from HIP events that
     # hipExtLaunchKernelGGL stamps with the dispatch's own begin / end times -- the quantity
@@ -381,7 +441,7 @@ def main():
         byts = algorithmic_bytes(M)
         k_dur = max(k_avg, 1e-9)
         ach_tflops = flops * ne_loc / k_dur / 1e12
-        kernel_name = "enhance_small_kernel<M=%d>" % M if M <= 14 else "enhance_large_kernel"
+        kernel_name = "enhance_small_kernel<M=%d>" % M if M <= 22 else "enhance_large_kernel"
         out = {
             "metric": "LSSVR-enhanced elements/sec, 1D Poisson deg-%d/%d-pt" % (args.degree, n),
             "value": total / elapsed,
@@ -410,8 +470,9 @@ def main():
             },
             "roofline": {
                 "bound": "mfma",
-                "pipe": "FP64 FMA (vector pipe at degree <= 12, f64 MFMA Gram above); on gfx950 the "
-                        "FP64 vector and matrix peaks are the same 78.6 TFLOP/s",
+                "pipe": "FP64: vector FMA at M <= 22, f64 MFMA (4x4x4 blocks) Gram + DPP-broadcast LDL^T "
+                        "above; on gfx950 the FP64 vector and matrix peaks are the same 78.6 TFLOP/s and "
+                        "the two share one pipe (DESIGN.md section 3)",
                 "kernel": kernel_name,
                 "achieved": ach_tflops,
                 "peak": FP64_PEAK_TFLOPS,
@@ -456,6 +517,8 @@ def main():
             out["cpu_baseline"] = cpu_res
         if stitch is not None:
             out["stitch"] = stitch
+        if stitch_u is not None:
+            out["stitch_u"] = stitch_u
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -103,44 +103,20 @@ __device__ __forceinline__ double sin_reduced_tab(double arg, const double* __re
 //   D: lane 16 i + 4 blk + j = D_blk[i][j]
 // A 16 x 16 tile of the Gram matrix is 4 x 4 blocks.  With A = the tile's row operand in the
 // layout above (block row blk = rows 4 blk .. 4 blk + 3) and B = the column operand ROTATED by r
-// quads inside every 16-lane row (DPP row_ror, two v_mov_dpp per double, no LDS), one
-// instruction yields the four blocks (blk, (blk + r) & 3).  A symmetric tile needs r = 0, 1, 2
-// (10 distinct blocks incl. mirrors), the off-diagonal tile r = 0 .. 3: 10 instructions per
-// 4 collocation points and element instead of 3 of the 16x16x4 kind -- 82 ns instead of 126.
-template <int R>
-__device__ __forceinline__ double row_rot_quads(double v) {
-  // out[m] = in[(m + 4 R) & 15] inside every row of 16 lanes: row_ror by 16 - 4 R
-  constexpr int ctrl = 0x120 + ((16 - 4 * R) & 15);
-  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-  const int lo = __builtin_amdgcn_mov_dpp((int)(unsigned)u, ctrl, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_mov_dpp((int)(unsigned)(u >> 32), ctrl, 0xf, 0xf, false);
-  return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
-}
-
+// quads inside every 16-lane row, one instruction yields the four blocks (blk, (blk + r) & 3).
+// The rotated operand is simply read from the LDS operand block with the rotated lane -> column
+// map (same conflict-free pattern as the plain read; a DPP row_ror of the register costs two
+// VALU movs per operand, and the kernel is bound by VALU issue: measured 8 % slower).
+// A symmetric tile needs r = 0, 1, 2 (10 distinct blocks incl. mirrors), the off-diagonal tile
+// r = 0 .. 3: 10 instructions per 4 collocation points and element instead of 3 of the
+// 16x16x4 kind -- 82 ns instead of 126.
 #define LSSVR_MFMA4(acc, av, bv) acc = __builtin_amdgcn_mfma_f64_4x4x4f64(av, bv, acc, 0, 0, 0)
 
-// the ten accumulators of one element: sym[0..2] tile (0,0) r = 0,1,2; off[0..3] tile (1,0);
-// low[0..2] tile (1,1)
+// the ten accumulators of one element: sym[0..2] tile (0,0) r = 0,1,2; off[0..3] tile (0,1)
+// (= tile (1,0) transposed); low[0..2] tile (1,1)
 struct GramAcc {
   double sym[3], off[4], low[3];
 };
-
-__device__ __forceinline__ void gram_step(GramAcc& g, double v0, double v1, bool need11) {
-  const double v0r1 = row_rot_quads<1>(v0), v0r2 = row_rot_quads<2>(v0), v0r3 = row_rot_quads<3>(v0);
-  LSSVR_MFMA4(g.sym[0], v0, v0);
-  LSSVR_MFMA4(g.sym[1], v0, v0r1);
-  LSSVR_MFMA4(g.sym[2], v0, v0r2);
-  LSSVR_MFMA4(g.off[0], v1, v0);
-  LSSVR_MFMA4(g.off[1], v1, v0r1);
-  LSSVR_MFMA4(g.off[2], v1, v0r2);
-  LSSVR_MFMA4(g.off[3], v1, v0r3);
-  if (need11) {
-    const double v1r1 = row_rot_quads<1>(v1), v1r2 = row_rot_quads<2>(v1);
-    LSSVR_MFMA4(g.low[0], v1, v1);
-    LSSVR_MFMA4(g.low[1], v1, v1r1);
-    LSSVR_MFMA4(g.low[2], v1, v1r2);
-  }
-}
 
 #define LSSVR_IS8(b) 1.0 / d2_scale(b), 1.0 / d2_scale(b + 1), 1.0 / d2_scale(b + 2), 1.0 / d2_scale(b + 3), \
                      1.0 / d2_scale(b + 4), 1.0 / d2_scale(b + 5), 1.0 / d2_scale(b + 6), 1.0 / d2_scale(b + 7)
@@ -241,7 +217,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 3) void enhance_large_kernel(E
 
     // ---- Gram contraction on the matrix cores ----------------------------------------
     GramAcc gA = {}, gB = {};
-    const int ar = (lane & 15) * kSB + (lane >> 4);
+    // operand addresses: rotation r reads column 4 ((blk + r) & 3) + j of the 16-column block
+    int ar[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      ar[r] = (4 * ((((lane >> 2) & 3) + r) & 3) + (lane & 3)) * kSB + (lane >> 4);
     for (int k0 = 0; k0 < n; k0 += kCH) {
       // (an opaque zero in the table index keeps the compiler from hoisting all 31 coefficient
       // loads out of the chunk loop, where they would occupy 62 SGPRs for the whole kernel)
@@ -301,20 +281,45 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 3) void enhance_large_kernel(E
       double a0[kCH / 4], b0[kCH / 4];
 #pragma unroll
       for (int s = 0; s < kCH / 4; ++s) {
-        a0[s] = BfA[ar + 4 * s];
-        b0[s] = BfB[ar + 4 * s];
+        a0[s] = BfA[ar[0] + 4 * s];
+        b0[s] = BfB[ar[0] + 4 * s];
+        const double a0r1 = BfA[ar[1] + 4 * s], a0r2 = BfA[ar[2] + 4 * s];
+        const double b0r1 = BfB[ar[1] + 4 * s], b0r2 = BfB[ar[2] + 4 * s];
+        LSSVR_MFMA4(gA.sym[0], a0[s], a0[s]);
+        LSSVR_MFMA4(gB.sym[0], b0[s], b0[s]);
+        LSSVR_MFMA4(gA.sym[1], a0[s], a0r1);
+        LSSVR_MFMA4(gB.sym[1], b0[s], b0r1);
+        LSSVR_MFMA4(gA.sym[2], a0[s], a0r2);
+        LSSVR_MFMA4(gB.sym[2], b0[s], b0r2);
       }
       wave_lds_sync();
 #pragma unroll
       for (int j = 16; j < kRhsRow; ++j) Bf[(j - 16) * kSB + c] = next_col(j);
       Bf[(kRhsRow - 16) * kSB + c] = phi;        // rhs always rides in the last column
       wave_lds_sync();
+      // tile (0,1) = rows 0..15 (kept operands) x columns 16..31 (this block), and tile (1,1)
 #pragma unroll
       for (int s = 0; s < kCH / 4; ++s) {
-        const double a1 = BfA[ar + 4 * s];
-        const double b1 = BfB[ar + 4 * s];
-        gram_step(gA, a0[s], a1, need11);
-        gram_step(gB, b0[s], b1, need11);
+        const double a1 = BfA[ar[0] + 4 * s], a1r1 = BfA[ar[1] + 4 * s];
+        const double a1r2 = BfA[ar[2] + 4 * s], a1r3 = BfA[ar[3] + 4 * s];
+        const double b1 = BfB[ar[0] + 4 * s], b1r1 = BfB[ar[1] + 4 * s];
+        const double b1r2 = BfB[ar[2] + 4 * s], b1r3 = BfB[ar[3] + 4 * s];
+        LSSVR_MFMA4(gA.off[0], a0[s], a1);
+        LSSVR_MFMA4(gB.off[0], b0[s], b1);
+        LSSVR_MFMA4(gA.off[1], a0[s], a1r1);
+        LSSVR_MFMA4(gB.off[1], b0[s], b1r1);
+        LSSVR_MFMA4(gA.off[2], a0[s], a1r2);
+        LSSVR_MFMA4(gB.off[2], b0[s], b1r2);
+        LSSVR_MFMA4(gA.off[3], a0[s], a1r3);
+        LSSVR_MFMA4(gB.off[3], b0[s], b1r3);
+        if (need11) {
+          LSSVR_MFMA4(gA.low[0], a1, a1);
+          LSSVR_MFMA4(gB.low[0], b1, b1);
+          LSSVR_MFMA4(gA.low[1], a1, a1r1);
+          LSSVR_MFMA4(gB.low[1], b1, b1r1);
+          LSSVR_MFMA4(gA.low[2], a1, a1r2);
+          LSSVR_MFMA4(gB.low[2], b1, b1r2);
+        }
       }
     }
 
@@ -335,8 +340,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 3) void enhance_large_kernel(E
     BfB[tcol[1] * kST + trow] = gB.sym[1];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      BfA[kT1 + trow * kST + tcol[r]] = gA.off[r];
-      BfB[kT1 + trow * kST + tcol[r]] = gB.off[r];
+      BfA[kT1 + tcol[r] * kST + trow] = gA.off[r];      // tile (1,0) = tile (0,1) transposed
+      BfB[kT1 + tcol[r] * kST + trow] = gB.off[r];
     }
     wave_lds_sync();
     // + eps on the diagonal of the MR x MR block (lane c owns G[c][c] of its element)

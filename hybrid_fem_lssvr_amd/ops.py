@@ -318,8 +318,9 @@ def p1_flux_finish(kloc, load, work, *, first_global, last_global, prefix=None, 
     return out
 
 
-def evaluate(x, W, xq, *, want_elem=True, stream=None):
-    """``evaluate_solution`` (Dual.py:176-203) -> (u float64[P], elem int64[P] | None)."""
+def evaluate(x, W, xq, *, want_elem=True, out=None, stream=None):
+    """``evaluate_solution`` (Dual.py:176-203) -> (u float64[P], elem int64[P] | None).
+    ``out``: optional preallocated float64[P] for u."""
     lib = _capi.load()
     _dev(x, "x")
     _dev(W, "W")
@@ -329,7 +330,12 @@ def evaluate(x, W, xq, *, want_elem=True, stream=None):
         raise ValueError("W must be [ne, M]")
     M = W.shape[1]
     P = xq.numel()
-    uq = torch.empty(P, dtype=torch.float64, device=x.device)
+    if out is None:
+        uq = torch.empty(P, dtype=torch.float64, device=x.device)
+    else:
+        uq = _dev(out, "out")
+        if uq.numel() != P or not uq.is_contiguous():
+            raise ValueError("out must be a contiguous float64[P] tensor")
     elem = torch.empty(P, dtype=torch.int64, device=x.device) if want_elem else None
     rc = lib.lssvr_eval(_ptr(x), _ptr(W), ne, int(M), _ptr(xq), P, _ptr(uq), _ptr(elem),
                         _stream(stream))
