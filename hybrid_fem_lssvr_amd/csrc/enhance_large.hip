@@ -36,6 +36,11 @@ namespace lssvr {
 using namespace wave;
 
 namespace {
+#ifndef LSSVR_LARGE_WAVES
+#define LSSVR_LARGE_WAVES 1
+#endif
+constexpr int kLargeWaves = LSSVR_LARGE_WAVES;   // waves per workgroup: they share nothing, and one-wave
+                                                 // workgroups free their LDS soonest (-2 % at 1e6 elements)
 constexpr int kSB = 34;                    // operand block: column stride (doubles)
 constexpr int kBlk = 16 * kSB;             // 544 = 16 columns x 32 points = two 16 x 17 tiles
 constexpr int kST = 17;                    // tile row stride
@@ -125,9 +130,9 @@ __device__ const double kInvScale2[kLP] = {LSSVR_IS8(0), LSSVR_IS8(8), LSSVR_IS8
 }  // namespace
 
 template <int RHS, bool VC>
-__global__ __launch_bounds__(kWavesPerBlock * 64, 3) void enhance_large_kernel(EnhanceArgs p,
+__global__ __launch_bounds__(kLargeWaves * 64, 3) void enhance_large_kernel(EnhanceArgs p,
                                                                                LargeTables tb) {
-  __shared__ double2_t lds2[kWavesPerBlock * kHalf2];      // 2 halves x kHalf2 doubles per wave
+  __shared__ double2_t lds2[kLargeWaves * kHalf2];      // 2 halves x kHalf2 doubles per wave
   double* const lds = reinterpret_cast<double*>(lds2);
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -144,7 +149,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 3) void enhance_large_kernel(E
   // one element pair per wave, no persistent loop: with a loop the compiler hoists ~70
   // VGPRs of lane constants (LDS addresses, series factors, sin coefficients) out of it and
   // spills them at the 168-register budget of three waves per SIMD
-  const int64_t pr = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  const int64_t pr = (int64_t)blockIdx.x * kLargeWaves + wave;
   if (pr >= npair) return;
   {
     const int64_t e_raw = 2 * pr + h;
@@ -417,9 +422,9 @@ hipError_t enhance_large(const EnhanceArgs& a, hipStream_t s, const LaunchOpts* 
   if (a.M - 2 + 1 > kLP) return hipErrorInvalidValue;
   static const LargeTables tables = make_large_tables();
   const int64_t npair = (a.ne + 1) / 2;
-  const int64_t blocks = (npair + kWavesPerBlock - 1) / kWavesPerBlock;
+  const int64_t blocks = (npair + kLargeWaves - 1) / kLargeWaves;
   if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-  const dim3 grid((unsigned)blocks), block(kWavesPerBlock * 64);
+  const dim3 grid((unsigned)blocks), block(kLargeWaves * 64);
   if (a.a_values)
     return launch(enhance_large_kernel<LSSVR_RHS_ARRAY, true>, grid, block, s, o, a, tables);
   if (a.rhs_id == LSSVR_RHS_SIN)

@@ -21,3 +21,7 @@ run sq_l2   --pmc SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFM
 python3 scripts/pmc_summary.py $O/fetch $O/write $O/fetchL $O/writeL $O/sq_s $O/sq_s2 $O/sq_s1m $O/sq_w9 $O/sq_l $O/sq_l2 > $O/pmc_summary.txt 2>&1
 cp $O/stats/*/*kernel_stats.csv $O/bench_kernel_stats.csv 2>/dev/null
 tail -n 60 $O/pmc_summary.txt
+# bench lines of the same build without the profiler attached
+python3 bench.py > $O/bench_n1.json 2> $O/bench_n1.err; echo "bench rc=$?"
+python3 bench.py --degree 32 --colloc 64 --elements 100000 --domain narrow --no-cpu-baseline > $O/bench_deg32.json 2> $O/bench_deg32.err; echo "bench32 rc=$?"
+python3 bench.py --elements 10000008 --no-cpu-baseline --steps 20 --warmup 3 > $O/bench_1e7.json 2> $O/bench_1e7.err; echo "bench1e7 rc=$?"
