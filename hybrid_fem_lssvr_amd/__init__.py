@@ -12,6 +12,7 @@ from .solver import (  # noqa: F401
     FEMLSSVRPrimalSolver,
     SinRHS,
     enhance_elements,
+    enhance_elements_hetero,
     lssvr_primal,
     main_boundary_condition_left,
     main_boundary_condition_right,

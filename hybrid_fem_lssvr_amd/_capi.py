@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # LSSVR_HIP_LIB selects another build of the same ABI (kernel A/B experiments)
 LIB_PATH = os.environ.get("LSSVR_HIP_LIB") or os.path.join(_HERE, "csrc", "liblssvr_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 RHS_ARRAY = 0
 RHS_SIN = 1
@@ -51,6 +51,11 @@ SIGNATURES = {
                                        _c_int, _c_int, _c_dbl,
                                        _c_dp, _c_dp, _c_dp,
                                        _c_dp, _c_dp, _c_dp, _c_dp]),
+    "lssvr_enhance_subset": (_c_int, [_c_dp, _c_dp, _c_i64, _c_dp, _c_i64, _c_i64, _c_i64,
+                                      _c_dbl, _c_dbl, _c_dbl, _c_dbl,
+                                      _c_int, _c_int, _c_dbl, _c_dp,
+                                      _c_int, C.POINTER(_c_dbl), _c_dp,
+                                      _c_dp, _c_i64, _c_dp, _c_dp, _c_dp]),
     "lssvr_colloc_points": (_c_int, [_c_dp, _c_i64, _c_int, _c_dp, _c_dp]),
     "lssvr_p1_assemble": (_c_int, [_c_dp, _c_i64, _c_int, _c_int, C.POINTER(_c_dbl), _c_dp, _c_dp,
                                    _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp]),

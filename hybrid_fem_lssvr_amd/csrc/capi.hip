@@ -210,6 +210,53 @@ int lssvr_enhance_varcoef(const double* x, const double* u, int64_t ne, int64_t 
   return check_launch(lssvr::enhance_large(a, s), "enhance_large(varcoef)");
 }
 
+int lssvr_enhance_subset(const double* x, const double* u, int64_t ne_mesh,
+                         const int64_t* elem_ids, int64_t nsub, int64_t elem_offset,
+                         int64_t ne_global, double gxmin, double gxmax, double bc_left,
+                         double bc_right, int M, int n_colloc, double gamma,
+                         const double* gamma_values, int rhs_id, const double* rhs_params_host,
+                         const double* rhs_values, double* W, int64_t ldw, int32_t* status,
+                         int32_t* fail_count, void* stream) {
+  if (ne_mesh < 0 || nsub < 0) return fail(LSSVR_ERR_SIZE, "ne_mesh / nsub < 0");
+  if (!elem_ids && nsub != ne_mesh)
+    return fail(LSSVR_ERR_SIZE, "elem_ids == NULL means every element: nsub must equal ne_mesh");
+  if (elem_ids && nsub > ne_mesh) return fail(LSSVR_ERR_SIZE, "nsub = %lld > ne_mesh = %lld",
+                                              (long long)nsub, (long long)ne_mesh);
+  if (ldw != 0 && ldw < M) return fail(LSSVR_ERR_SIZE, "ldw = %lld < M = %d", (long long)ldw, M);
+  if (ne_global < elem_offset + ne_mesh)
+    return fail(LSSVR_ERR_SIZE, "shard [%lld, %lld) does not fit ne_global = %lld",
+                (long long)elem_offset, (long long)(elem_offset + ne_mesh), (long long)ne_global);
+  lssvr::EnhanceArgs a;
+  // (the shard check of fill_enhance_args is on the subset size here: done above for the mesh)
+  int rc = fill_enhance_args(a, x, u, nsub, elem_offset, ne_global, gxmin, gxmax, bc_left, bc_right,
+                             M, n_colloc, gamma_values ? 1.0 : gamma, W);
+  if (rc != LSSVR_OK) return rc;
+  if (n_colloc < M - 2)
+    return fail(LSSVR_ERR_SOLVER, "lssvr_enhance_subset: n_colloc < M-2 needs the dual solver, "
+                                  "which has no subset form");
+  a.gamma = gamma;
+  a.elem_ids = elem_ids;
+  a.gamma_values = gamma_values;
+  a.ldw = ldw;
+  a.rhs_id = rhs_id;
+  if (rhs_id == LSSVR_RHS_SIN) {
+    if (!rhs_params_host) return fail(LSSVR_ERR_RHS, "LSSVR_RHS_SIN needs rhs_params = {amp, omega}");
+    a.rhs_amp = rhs_params_host[0];
+    a.rhs_omega = rhs_params_host[1];
+  } else if (rhs_id == LSSVR_RHS_ARRAY) {
+    if (nsub > 0 && !rhs_values) return fail(LSSVR_ERR_RHS, "LSSVR_RHS_ARRAY needs rhs_values[nsub*n_colloc]");
+    a.rhs_values = rhs_values;
+  } else {
+    return fail(LSSVR_ERR_RHS, "unknown rhs_id %d", rhs_id);
+  }
+  a.status = status;
+  a.fail_count = fail_count;
+  if (nsub == 0) return LSSVR_OK;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (M <= lssvr::kSmallMaxM) return check_launch(lssvr::enhance_small(a, s), "enhance_small(subset)");
+  return check_launch(lssvr::enhance_large(a, s), "enhance_large(subset)");
+}
+
 int lssvr_colloc_points(const double* x, int64_t ne, int n_colloc, double* xc, void* stream) {
   if (ne < 0) return fail(LSSVR_ERR_SIZE, "ne < 0");
   if (n_colloc < 2) return fail(LSSVR_ERR_SIZE, "n_colloc < 2");

@@ -155,16 +155,18 @@ __global__ __launch_bounds__(kLargeWaves * 64, 3) void enhance_large_kernel(Enha
     const int64_t e_raw = 2 * pr + h;
     const bool live = e_raw < p.ne;               // odd ne: half 1 of the last pair idles
     const int64_t e = live ? e_raw : p.ne - 1;    // ... on a duplicate, stores masked
-    const double a = p.x[e];
-    const double b = p.x[e + 1];
-    const int64_t eg = e + p.elem_offset;
-    const double gl = (eg == 0 && a == p.gxmin) ? p.bc_left : p.u[e];
-    const double gr = (eg == p.ne_global - 1 && b == p.gxmax) ? p.bc_right : p.u[e + 1];
+    const int64_t id = p.elem_ids ? p.elem_ids[e] : e;     // mesh index (lssvr_enhance_subset)
+    const double a = p.x[id];
+    const double b = p.x[id + 1];
+    const int64_t eg = id + p.elem_offset;
+    const double gl = (eg == 0 && a == p.gxmin) ? p.bc_left : p.u[id];
+    const double gr = (eg == p.ne_global - 1 && b == p.gxmax) ? p.bc_right : p.u[id + 1];
+    const double gamma = p.gamma_values ? p.gamma_values[id] : p.gamma;
     const DomainMap dm = map_params(a, b);
     const double step = dm.oldlen / (double)(n - 1);
     const double scl2 = dm.scl * dm.scl;
     const double inv_scl2 = rcp_newton(scl2);
-    const double eps = rcp_newton(p.gamma * (scl2 * scl2));
+    const double eps = rcp_newton(gamma * (scl2 * scl2));
 
     // ---- boundary rows: lane c holds L_{c+2}(ta), L_{c+2}(tb) of its element ----------
     const double ta = dm.off + dm.scl * a;
@@ -406,12 +408,12 @@ __global__ __launch_bounds__(kLargeWaves * 64, 3) void enhance_large_kernel(Enha
 
     // ---- store: lane c -> W[e][c+2]; lane 0 also writes w0, w1 -----------------------------
     if (live) {
-      double* const Wrow = p.W + e * M;
+      double* const Wrow = p.W + id * (p.ldw ? p.ldw : (int64_t)M);
       if (c < MR) Wrow[c + 2] = ok ? v * isc : 0.0;    // w = D^-1 v'
       if (c == 0) {
         Wrow[0] = ok ? w0 : 0.5 * (gl + gr);
         Wrow[1] = ok ? w1 : 0.5 * (gr - gl);
-        if (p.status) p.status[e] = ok ? LSSVR_ST_OK : LSSVR_ST_FALLBACK;
+        if (p.status) p.status[id] = ok ? LSSVR_ST_OK : LSSVR_ST_FALLBACK;
         if (!ok && p.fail_count) atomicAdd(p.fail_count, 1);
       }
     }

@@ -42,21 +42,24 @@ __device__ __forceinline__ void enhance_small_body(const EnhanceArgs& p, const u
 #pragma unroll
   for (int i = 0; i < M; ++i) w[i] = 0.0;
 
+  const bool scattered = p.elem_ids != nullptr || (p.ldw != 0 && p.ldw != M);
   if (e < p.ne) {
-    const double a = p.x[e];
-    const double b = p.x[e + 1];
-    const int64_t eg = e + p.elem_offset;
+    const int64_t id = p.elem_ids ? p.elem_ids[e] : e;      // mesh index of this element
+    const double a = p.x[id];
+    const double b = p.x[id + 1];
+    const int64_t eg = id + p.elem_offset;
     // Dual.py:65-75: Dirichlet value only on a global-boundary element whose end
     // point equals the global end point exactly
-    const double gl = (eg == 0 && a == p.gxmin) ? p.bc_left : p.u[e];
-    const double gr = (eg == p.ne_global - 1 && b == p.gxmax) ? p.bc_right : p.u[e + 1];
+    const double gl = (eg == 0 && a == p.gxmin) ? p.bc_left : p.u[id];
+    const double gr = (eg == p.ne_global - 1 && b == p.gxmax) ? p.bc_right : p.u[id + 1];
+    const double gamma = p.gamma_values ? p.gamma_values[id] : p.gamma;
 
     const DomainMap dm = map_params(a, b);
     const int n = p.n;
     const double step = dm.oldlen / (double)(n - 1);
     const double scl2 = dm.scl * dm.scl;
     const double inv_scl2 = rcp_newton(scl2);
-    const double eps = rcp_newton(p.gamma * (scl2 * scl2));   // 1 / (gamma * scl^4)
+    const double eps = rcp_newton(gamma * (scl2 * scl2));   // 1 / (gamma * scl^4)
 
     // --- boundary rows (Dual.py:61-76): B = [L_p(t_a); L_p(t_b)], eliminated as
     // w_{0,1} = d - C v with B1 = [[1, ta], [1, tb]], B1^{-1} = [[tb, -ta], [-1, 1]]/(tb - ta).
@@ -228,8 +231,15 @@ __device__ __forceinline__ void enhance_small_body(const EnhanceArgs& p, const u
       w[1] = 0.5 * (gr - gl);
       if (p.fail_count) atomicAdd(p.fail_count, 1);
     }
-    if (p.status) p.status[e] = st;
+    if (p.status) p.status[id] = st;
+    if (scattered) {
+      // heterogeneous launch: rows go to the mesh index, ldw apart (direct stores)
+      double* const Wrow = p.W + id * (p.ldw ? p.ldw : (int64_t)M);
+#pragma unroll
+      for (int i = 0; i < M; ++i) Wrow[i] = w[i];
+    }
   }
+  if (scattered) return;
 
   // --- coalesced store: each wave transposes its own 64 x M tile through LDS --------
   // (wave-private, so no workgroup barrier: a wave that finishes early stores early;

@@ -21,6 +21,14 @@ struct EnhanceArgs {
   const double* rhs_values;
   const double* a_values;   // non-null => variable-coefficient rows
   const double* da_values;
+  // heterogeneous launches (lssvr_enhance_subset): local element k of the launch is mesh
+  // element elem_ids[k] (NULL: k itself) -- node / nodal-value / gamma_values / status / W
+  // rows are addressed by the MESH index, the tabulated arrays (rhs_values, a_values,
+  // da_values) by k; gamma_values[mesh index] replaces gamma when non-NULL; W rows are ldw
+  // doubles apart (0 = M)
+  const int64_t* elem_ids;
+  const double* gamma_values;
+  int64_t ldw;
   double* W;
   int32_t* status;
   int32_t* fail_count;

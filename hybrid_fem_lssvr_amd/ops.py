@@ -96,6 +96,54 @@ def enhance(x, u, M, gamma, n_colloc=12, *, rhs=(POISSON_AMP, POISSON_OMEGA), rh
     return out, status
 
 
+def enhance_subset(x, u, M, gamma, n_colloc, W, *, elem_ids=None, gamma_values=None,
+                   rhs=(POISSON_AMP, POISSON_OMEGA), rhs_values=None, elem_offset=0, ne_global=None,
+                   global_domain, bc=(0.0, 0.0), status=None, fail_count=None, stream=None):
+    """``lssvr_enhance_subset``: the elements ``elem_ids`` (int64 device tensor of mesh indices;
+    None = all) of the shard (x, u) with one (M, n_colloc); per-element ``gamma_values``
+    (float64[ne], indexed by mesh element) optional.  Rows go to ``W[id, :M]`` of the caller's
+    float64[ne, ldw] array (ldw = W.shape[1] >= M; zero it first when ldw > M)."""
+    lib = _capi.load()
+    _dev(x, "x")
+    _dev(u, "u")
+    _dev(W, "W")
+    ne = x.numel() - 1
+    if W.dim() != 2 or W.shape[0] != ne or W.shape[1] < M or not W.is_contiguous():
+        raise ValueError("W must be a contiguous float64[ne, ldw >= M] tensor")
+    if elem_ids is not None:
+        _dev(elem_ids, "elem_ids", torch.int64)
+        nsub = elem_ids.numel()
+    else:
+        nsub = ne
+    if gamma_values is not None:
+        _dev(gamma_values, "gamma_values")
+        if gamma_values.numel() != ne:
+            raise ValueError("gamma_values must hold one value per mesh element")
+    if status is not None:
+        _dev(status, "status", torch.int32)
+        if status.numel() != ne:
+            raise ValueError("status is indexed by mesh element: int32[ne]")
+    if fail_count is not None:
+        _dev(fail_count, "fail_count", torch.int32)
+    if ne_global is None:
+        ne_global = elem_offset + ne
+    if rhs_values is not None:
+        _dev(rhs_values, "rhs_values")
+        if rhs_values.numel() != nsub * n_colloc:
+            raise ValueError("rhs_values must hold nsub*n_colloc doubles (indexed by position in elem_ids)")
+        rhs_id, params = RHS_ARRAY, None
+    else:
+        rhs_id, params = RHS_SIN, _capi.rhs_params(*rhs)
+    rc = lib.lssvr_enhance_subset(_ptr(x), _ptr(u), ne, _ptr(elem_ids), int(nsub), int(elem_offset),
+                                  int(ne_global), float(global_domain[0]), float(global_domain[1]),
+                                  float(bc[0]), float(bc[1]), int(M), int(n_colloc), float(gamma),
+                                  _ptr(gamma_values), rhs_id, params, _ptr(rhs_values),
+                                  _ptr(W), int(W.shape[1]), _ptr(status), _ptr(fail_count),
+                                  _stream(stream))
+    _capi.check(rc, "lssvr_enhance_subset")
+    return W
+
+
 def enhance_profiled(x, u, M, gamma, n_colloc=12, *, rhs=(POISSON_AMP, POISSON_OMEGA),
                      elem_offset=0, ne_global=None, global_domain, bc=(0.0, 0.0),
                      solver=SOLVER_PRIMAL, out=None, status=None, stream=None):

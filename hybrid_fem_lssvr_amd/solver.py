@@ -175,6 +175,50 @@ def enhance_elements(mesh, nodal_values, M, gamma, *, n_colloc=12, rhs=poisson_r
     return EnhancedSolution(x, W, st)
 
 
+def enhance_elements_hetero(mesh, nodal_values, M, gamma, *, n_colloc=12, rhs=poisson_rhs,
+                            global_domain=None, bc=(0.0, 0.0), device="cuda:0"):
+    """Per-element ``M`` / ``gamma`` / ``n_colloc`` (the reference has one
+    ``lssvr_M`` / ``lssvr_gamma`` per mesh, Dual.py:101).  Each of the three is a scalar or an
+    array with one entry per element.  Elements are grouped by (M, n_colloc); every group is
+    one ``lssvr_enhance_subset`` launch writing straight into the rows of a zero-padded
+    ``W[ne, max M]`` (a Legendre series with trailing zeros evaluates identically), so
+    ``EnhancedSolution.evaluate`` works unchanged.  ``lssvr_functions``-style access:
+    ``Legendre(W[i, :M_i], [x_i, x_{i+1}])``."""
+    torch = _torch()
+    dev = _device(device)
+    m = as_line_mesh(mesh)
+    ne = m.nelements
+    x = _to_dev(m.nodes, dev)
+    u = _to_dev(nodal_values, dev)
+    if u.numel() != x.numel():
+        raise ValueError("nodal_values must have one value per mesh node")
+    if global_domain is None:
+        global_domain = (float(m.nodes[0]), float(m.nodes[-1]))
+    Ms = np.broadcast_to(np.asarray(M, dtype=np.int64), (ne,))
+    ns = np.broadcast_to(np.asarray(n_colloc, dtype=np.int64), (ne,))
+    gs = np.array(np.broadcast_to(np.asarray(gamma, dtype=np.float64), (ne,)))
+    if np.any(gs <= 0):
+        raise ValueError("gamma must be > 0 for every element")
+    W = torch.zeros((ne, int(Ms.max())), dtype=torch.float64, device=dev)
+    st = torch.zeros((ne,), dtype=torch.int32, device=dev)
+    gv = _to_dev(gs, dev)
+    for Mg, ng in sorted({(int(a), int(b)) for a, b in zip(Ms, ns)}):
+        ids_h = np.nonzero((Ms == Mg) & (ns == ng))[0].astype(np.int64)
+        ids = torch.as_tensor(ids_h, device=dev)
+        if isinstance(rhs, SinRHS):
+            kw = dict(rhs=(rhs.amp, rhs.omega))
+        else:
+            # tabulate f at this group's collocation points (np.linspace per element)
+            xc = ops.colloc_points(x, ng)[ids]
+            f = np.asarray(rhs(xc.cpu().numpy()), dtype=np.float64)
+            kw = dict(rhs_values=_to_dev(np.broadcast_to(f, tuple(xc.shape)), dev))
+        ops.enhance_subset(x, u, Mg, 1.0, ng, W, elem_ids=ids, gamma_values=gv,
+                           global_domain=global_domain, bc=bc, status=st, **kw)
+    sol = EnhancedSolution(x, W, st)
+    sol.degrees = Ms.copy()
+    return sol
+
+
 # --------------------------------------------------------------------------
 # lssvr_primal (Dual.py:20-98)
 # --------------------------------------------------------------------------

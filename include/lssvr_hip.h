@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LSSVR_ABI_VERSION 1
+#define LSSVR_ABI_VERSION 2
 
 /* error codes */
 #define LSSVR_OK              0
@@ -124,7 +124,7 @@ int lssvr_enhance_profiled(const double* x, const double* u, int64_t ne,
 /*
  * lssvr_step -- one whole step of the hot path on one mesh shard in ONE launch:
  * lssvr_p1_assemble (in-kernel rhs, nquad-point Gauss) + lssvr_enhance (primal
- * solver, in-kernel rhs).  For M <= 14 the two run as disjoint block ranges of a single
+ * solver, in-kernel rhs).  For M <= 22 the two run as disjoint block ranges of a single
  * grid; arguments as in the two separate calls.
  */
 int lssvr_step(const double* x, const double* u, int64_t ne,
@@ -148,6 +148,30 @@ int lssvr_enhance_varcoef(const double* x, const double* u, int64_t ne,
                           const double* a_values, const double* da_values,
                           const double* rhs_values,
                           double* W, int32_t* status, int32_t* fail_count, void* stream);
+
+/*
+ * lssvr_enhance_subset -- heterogeneous meshes (per-element gamma, degree and
+ * collocation count; the reference has one lssvr_M / lssvr_gamma for the whole mesh,
+ * Dual.py:101).  Enhances the nsub elements elem_ids[0..nsub) of a shard of ne_mesh elements
+ * with ONE (M, n_colloc); a p-adaptive mesh is one call per distinct (M, n_colloc) group.
+ *   elem_ids[nsub]       device int64 mesh indices, each in [0, ne_mesh) and distinct
+ *                        (NULL = all elements in order; nsub must then equal ne_mesh)
+ *   gamma_values[ne_mesh] device, indexed by MESH element (NULL = the scalar gamma)
+ *   rhs_values[nsub*n_colloc]  (LSSVR_RHS_ARRAY) indexed by position k in elem_ids
+ *   W, ldw               row of mesh element id starts at W + id*ldw (ldw >= M; 0 = M): with
+ *                        ldw = max M of the mesh and W zeroed beforehand every row is a valid
+ *                        Legendre series for lssvr_eval (trailing zeros change nothing)
+ *   status[ne_mesh]      indexed by mesh element (may be NULL)
+ * Primal solver only (n_colloc >= M-2).  x, u, elem_offset, ne_global, ... as lssvr_enhance.
+ */
+int lssvr_enhance_subset(const double* x, const double* u, int64_t ne_mesh,
+                         const int64_t* elem_ids, int64_t nsub,
+                         int64_t elem_offset, int64_t ne_global,
+                         double gxmin, double gxmax, double bc_left, double bc_right,
+                         int M, int n_colloc, double gamma, const double* gamma_values,
+                         int rhs_id, const double* rhs_params_host, const double* rhs_values,
+                         double* W, int64_t ldw, int32_t* status, int32_t* fail_count,
+                         void* stream);
 
 /*
  * lssvr_colloc_points -- x_k of every element exactly as `np.linspace(xmin, xmax, n)`

@@ -1,0 +1,100 @@
+"""GPU parity tests of the heterogeneous-mesh entry (lssvr_enhance_subset):
+per-element gamma, degree and collocation count on non-uniform meshes.  The reference has one
+(lssvr_M, lssvr_gamma) per mesh (Dual.py:101) and a uniform mesh (Dual.py:112), so there is no
+reference output for a mixed mesh: every element is checked against the float64 oracle solve of
+ITS OWN problem (the same per-element QP the golden tests pin), i.e. parity per element."""
+import numpy as np
+import pytest
+from numpy.polynomial.legendre import Legendre
+
+from oracle import lssvr_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_element(nodes, values, i, M, gamma, n, gd):
+    ne = len(nodes) - 1
+    gl, gr = orc.boundary_values(i, ne, nodes[i], nodes[i + 1], values[i], values[i + 1], gd)
+    return orc.solve_primal_kkt(orc.element_system(nodes[i], nodes[i + 1], gl, gr, M, gamma, n))
+
+
+def _mesh(ne, seed):
+    rng = np.random.default_rng(seed)
+    nodes = np.cumsum(np.concatenate([[-1.3], rng.uniform(0.02, 0.09, ne)]))
+    values = np.sin(np.pi * nodes) + 0.02 * rng.standard_normal(ne + 1)
+    return rng, nodes, values
+
+
+def test_per_element_gamma(dev):
+    import hybrid_fem_lssvr_amd as pkg
+    rng, nodes, values = _mesh(300, 11)
+    ne = 300
+    gam = 10.0 ** rng.uniform(2, 7, ne)
+    sol = pkg.enhance_elements_hetero(nodes, values, 9, gam, n_colloc=16)
+    W = sol.W.cpu().numpy()
+    assert sol.n_fallback == 0
+    gd = (nodes[0], nodes[-1])
+    for i in range(ne):
+        wo = _oracle_element(nodes, values, i, 9, gam[i], 16, gd)
+        assert orc.rel_l2_coef(W[i][None], wo[None]).max() <= 1e-12, i
+
+
+def test_mixed_degree_and_colloc(dev):
+    import hybrid_fem_lssvr_amd as pkg
+    rng, nodes, values = _mesh(240, 12)
+    ne = 240
+    choices = [(5, 8), (9, 16), (12, 12), (14, 20), (22, 40), (25, 48), (33, 64)]
+    pick = rng.integers(0, len(choices), ne)
+    Ms = np.array([choices[k][0] for k in pick])
+    ns = np.array([choices[k][1] for k in pick])
+    gam = 10.0 ** rng.uniform(3, 5, ne)
+    sol = pkg.enhance_elements_hetero(nodes, values, Ms, gam, n_colloc=ns)
+    W = sol.W.cpu().numpy()
+    assert W.shape == (ne, 33) and sol.n_fallback == 0
+    gd = (nodes[0], nodes[-1])
+    for i in range(ne):
+        wo = _oracle_element(nodes, values, i, int(Ms[i]), gam[i], int(ns[i]), gd)
+        assert np.all(W[i, Ms[i]:] == 0.0)
+        tol = 1e-12 if Ms[i] <= 22 else 1e-11
+        assert orc.rel_l2_coef(W[i, :Ms[i]][None], wo[None]).max() <= tol, (i, Ms[i])
+    # the padded rows evaluate like the per-element numpy series (Dual.py:176-203 rule)
+    xq = np.sort(rng.uniform(nodes[0], nodes[-1], 500))
+    uq, elem = sol.evaluate(xq, return_elements=True)
+    ref = np.array([Legendre(W[e, :Ms[e]], [nodes[e], nodes[e + 1]])(x) for x, e in zip(xq, elem)])
+    assert np.max(np.abs(uq - ref)) <= 1e-13 * max(1.0, np.max(np.abs(ref)))
+
+
+def test_subset_leaves_other_rows_alone(dev):
+    import torch
+    from hybrid_fem_lssvr_amd import ops
+    _, nodes, values = _mesh(130, 13)
+    x = torch.as_tensor(nodes, device=dev)
+    u = torch.as_tensor(values, device=dev)
+    gd = (nodes[0], nodes[-1])
+    for M, n in [(9, 16), (33, 64)]:
+        W = torch.full((130, M + 3), 7.0, dtype=torch.float64, device=dev)
+        st = torch.full((130,), -5, dtype=torch.int32, device=dev)
+        ids = torch.as_tensor(np.array([129, 0, 64, 3, 77], dtype=np.int64), device=dev)
+        ops.enhance_subset(x, u, M, 1e4, n, W, elem_ids=ids, global_domain=gd, status=st)
+        torch.cuda.synchronize()
+        Wh, sth = W.cpu().numpy(), st.cpu().numpy()
+        touched = np.zeros(130, dtype=bool)
+        touched[[129, 0, 64, 3, 77]] = True
+        assert np.all(Wh[~touched] == 7.0) and np.all(sth[~touched] == -5)
+        assert np.all(Wh[touched][:, M:] == 7.0) and np.all(sth[touched] == 0)
+        Wfull, _ = ops.enhance(x, u, M, 1e4, n, global_domain=gd)
+        assert np.array_equal(Wh[touched][:, :M], Wfull.cpu().numpy()[touched])
+
+
+def test_subset_argument_errors(dev):
+    import torch
+    from hybrid_fem_lssvr_amd import ops, _capi
+    _, nodes, values = _mesh(20, 14)
+    x = torch.as_tensor(nodes, device=dev)
+    u = torch.as_tensor(values, device=dev)
+    W = torch.zeros((20, 9), dtype=torch.float64, device=dev)
+    with pytest.raises(ValueError):
+        ops.enhance_subset(x, u, 12, 1e4, 16, W, global_domain=(nodes[0], nodes[-1]))   # ldw < M
+    W = torch.zeros((20, 12), dtype=torch.float64, device=dev)
+    with pytest.raises(_capi.LssvrHipError):
+        ops.enhance_subset(x, u, 12, 1e4, 5, W, global_domain=(nodes[0], nodes[-1]))    # n < M-2
