@@ -359,6 +359,34 @@ def main():
                   "value": nn * args.steps / tn, "ms_per_step": tn / args.steps * 1e3,
                   "fallback_elements": int(pl.status.sum().item())}
 
+    # the uniform-mesh shortcut (lssvr_enhance_shared; SURVEY.md 8(d): "reported as a separate line
+    # if built"): one shared operator applied per element.  Never part of `value`; its own
+    # roofline is HBM (88 B per element against ~8 TB/s).
+    shared = None
+    if rank == 0 and M <= 16 and args.domain == "wide":
+        try:
+            op = ops.build_shared_operator(1.0 / 12.0, M, GAMMA, n, device=dev)
+            Ws = torch.empty((ne_loc, M), dtype=torch.float64, device=dev)
+            ts = sorted(ops.enhance_shared(x, u, op, M, n, elem_offset=s0, ne_global=ne_glob,
+                                           global_domain=gd, out=Ws, status=status, profiled=True)
+                        for _ in range(min(args.steps, 50)))
+            t_sh = sum(ts) / len(ts)
+            diff = (Ws - W[:ne_loc]).double()
+            rel = float((diff.pow(2).sum(1).sqrt() / W[:ne_loc].pow(2).sum(1).sqrt().clamp_min(1e-300)).max().item())
+            shared = {
+                "what": "lssvr_enhance_shared: uniform mesh, one (n+2) x M operator (built by the general "
+                        "kernel) applied per element; same inputs, same W layout",
+                "value": ne_loc / t_sh, "unit": "elements/s", "kernel_us_avg": t_sh * 1e6,
+                "kernel_us_median": ts[len(ts) // 2] * 1e6,
+                "roofline": {"bound": "hbm", "achieved": algorithmic_bytes(M) * ne_loc / t_sh / 1e9,
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": algorithmic_bytes(M) * ne_loc / t_sh / 1e9 / HBM_PEAK_GBS,
+                             "bytes_per_element": algorithmic_bytes(M)},
+                "max_rel_coef_diff_vs_general_kernel": rel,
+            }
+        except Exception as exc:  # pragma: no cover
+            shared = {"error": repr(exc)}
+
     # the stages around the hot path, each timed on its own (t_global_solve,
     # t_eval, H2D/D2H are reported separately and never enter `value`)
     stages = None
@@ -511,6 +539,8 @@ def main():
             out["stages"] = stages
         if narrow is not None:
             out["narrow_domain"] = narrow
+        if shared is not None:
+            out["shared_operator"] = shared
         if accuracy is not None:
             out["accuracy"] = accuracy
         if cpu_res is not None:

@@ -56,6 +56,11 @@ SIGNATURES = {
                                       _c_int, _c_int, _c_dbl, _c_dp,
                                       _c_int, C.POINTER(_c_dbl), _c_dp,
                                       _c_dp, _c_i64, _c_dp, _c_dp, _c_dp]),
+    "lssvr_enhance_shared": (_c_int, [_c_dp, _c_dp, _c_i64, _c_i64, _c_i64,
+                                      _c_dbl, _c_dbl, _c_dbl, _c_dbl,
+                                      _c_int, _c_int,
+                                      _c_int, C.POINTER(_c_dbl), _c_dp, _c_dp,
+                                      _c_dp, _c_dp, _c_dp, _c_dp, C.POINTER(C.c_float)]),
     "lssvr_colloc_points": (_c_int, [_c_dp, _c_i64, _c_int, _c_dp, _c_dp]),
     "lssvr_p1_assemble": (_c_int, [_c_dp, _c_i64, _c_int, _c_int, C.POINTER(_c_dbl), _c_dp, _c_dp,
                                    _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp]),

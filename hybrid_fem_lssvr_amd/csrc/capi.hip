@@ -257,6 +257,49 @@ int lssvr_enhance_subset(const double* x, const double* u, int64_t ne_mesh,
   return check_launch(lssvr::enhance_large(a, s), "enhance_large(subset)");
 }
 
+int lssvr_enhance_shared(const double* x, const double* u, int64_t ne, int64_t elem_offset,
+                         int64_t ne_global, double gxmin, double gxmax, double bc_left,
+                         double bc_right, int M, int n_colloc, int rhs_id,
+                         const double* rhs_params_host, const double* rhs_values, const double* op,
+                         double* W, int32_t* status, int32_t* fail_count, void* stream,
+                         float* kernel_ms_host) {
+  lssvr::EnhanceArgs a;
+  int rc = fill_enhance_args(a, x, u, ne, elem_offset, ne_global, gxmin, gxmax, bc_left, bc_right,
+                             M, n_colloc, 1.0, W);
+  if (rc != LSSVR_OK) return rc;
+  if (M > lssvr::kSharedMaxM)
+    return fail(LSSVR_ERR_DEGREE, "shared-operator path: M = %d > %d", M, lssvr::kSharedMaxM);
+  if (ne > 0 && !op) return fail(LSSVR_ERR_NULL, "op[(n_colloc+2)*M] must be non-NULL");
+  a.rhs_id = rhs_id;
+  if (rhs_id == LSSVR_RHS_SIN) {
+    if (!rhs_params_host) return fail(LSSVR_ERR_RHS, "LSSVR_RHS_SIN needs rhs_params = {amp, omega}");
+    a.rhs_amp = rhs_params_host[0];
+    a.rhs_omega = rhs_params_host[1];
+  } else if (rhs_id == LSSVR_RHS_ARRAY) {
+    if (ne > 0 && !rhs_values) return fail(LSSVR_ERR_RHS, "LSSVR_RHS_ARRAY needs rhs_values[ne*n_colloc]");
+    a.rhs_values = rhs_values;
+  } else {
+    return fail(LSSVR_ERR_RHS, "unknown rhs_id %d", rhs_id);
+  }
+  a.status = status;
+  a.fail_count = fail_count;
+  if (ne == 0) return LSSVR_OK;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (!kernel_ms_host) return check_launch(lssvr::enhance_shared(a, op, s), "enhance_shared");
+  lssvr::LaunchOpts o;
+  if (hipEventCreate(&o.start) != hipSuccess || hipEventCreate(&o.stop) != hipSuccess)
+    return fail(LSSVR_ERR_LAUNCH, "hipEventCreate failed");
+  rc = check_launch(lssvr::enhance_shared(a, op, s, &o), "enhance_shared(profiled)");
+  if (rc == LSSVR_OK) {
+    if (hipEventSynchronize(o.stop) != hipSuccess ||
+        hipEventElapsedTime(kernel_ms_host, o.start, o.stop) != hipSuccess)
+      rc = fail(LSSVR_ERR_LAUNCH, "event timing failed");
+  }
+  (void)hipEventDestroy(o.start);
+  (void)hipEventDestroy(o.stop);
+  return rc;
+}
+
 int lssvr_colloc_points(const double* x, int64_t ne, int n_colloc, double* xc, void* stream) {
   if (ne < 0) return fail(LSSVR_ERR_SIZE, "ne < 0");
   if (n_colloc < 2) return fail(LSSVR_ERR_SIZE, "n_colloc < 2");

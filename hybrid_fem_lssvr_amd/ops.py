@@ -14,6 +14,8 @@ import torch
 from . import _capi
 from ._capi import RHS_ARRAY, RHS_SIN, SOLVER_DUAL, SOLVER_PRIMAL, SOLVER_PRIMAL_WAVE  # noqa: F401
 
+SOLVER_SHARED = 100      # facade-level choice for UNIFORM meshes: routed to lssvr_enhance_shared
+
 POISSON_AMP = float(math.pi ** 2)     # Dual.py:12  np.pi**2
 POISSON_OMEGA = float(math.pi)
 
@@ -142,6 +144,74 @@ def enhance_subset(x, u, M, gamma, n_colloc, W, *, elem_ids=None, gamma_values=N
                                   _stream(stream))
     _capi.check(rc, "lssvr_enhance_subset")
     return W
+
+
+def build_shared_operator(h, M, gamma, n_colloc, *, device="cuda:0", stream=None):
+    """Response table of ONE canonical element of length ``h`` for :func:`enhance_shared`:
+    float64[n_colloc + 2, M], built by the general per-element kernel (``lssvr_enhance``) on a
+    (n_colloc + 2)-element auxiliary mesh of the same spacing centred on 0 -- unit right-hand
+    sides for rows k < n, unit boundary values for the last two rows."""
+    n = int(n_colloc)
+    h = float(h)
+    nel = n + 2
+    nodes = (torch.arange(nel + 1, dtype=torch.float64) - 0.5 * nel) * h
+    scl = 2.0 / float(nodes[1] - nodes[0])
+    f = torch.zeros((nel, n), dtype=torch.float64)
+    f[torch.arange(n), torch.arange(n)] = scl * scl          # f~ = f / scl^2 = e_k
+    uu = torch.zeros(nel + 1, dtype=torch.float64)
+    uu[n + 1] = 1.0                # element n: (g_l, g_r) = (0, 1); element n+1: (1, 0)
+    x = nodes.to(device)
+    W, st = enhance(x, uu.to(device), int(M), float(gamma), n, rhs_values=f.to(device),
+                    elem_offset=1, ne_global=nel + 2, global_domain=(float(nodes[0]) - h, float(nodes[-1]) + h),
+                    stream=stream)
+    op = torch.empty((nel, M), dtype=torch.float64, device=device)
+    op[:n] = W[:n]
+    op[n] = W[n + 1]               # response to g_l
+    op[n + 1] = W[n]               # response to g_r
+    if int(st.sum().item()) != 0:
+        raise _capi.LssvrHipError("build_shared_operator: the canonical element's factorisation broke down")
+    return op
+
+
+def enhance_shared(x, u, op, M, n_colloc, *, rhs=(POISSON_AMP, POISSON_OMEGA), rhs_values=None,
+                   elem_offset=0, ne_global=None, global_domain, bc=(0.0, 0.0), out=None, status=None,
+                   fail_count=None, stream=None, profiled=False):
+    """``lssvr_enhance_shared`` (uniform meshes; the caller vouches for uniformity).  Returns
+    (W, status), or the kernel duration in seconds when ``profiled``."""
+    import ctypes
+    lib = _capi.load()
+    _dev(x, "x")
+    _dev(u, "u")
+    _dev(op, "op")
+    ne = x.numel() - 1
+    if op.numel() != (n_colloc + 2) * M or not op.is_contiguous():
+        raise ValueError("op must be a contiguous float64[(n_colloc+2), M] tensor")
+    if ne_global is None:
+        ne_global = elem_offset + ne
+    if out is None:
+        out = torch.empty((ne, M), dtype=torch.float64, device=x.device)
+    else:
+        _dev(out, "out")
+    if status is None:
+        status = torch.empty((ne,), dtype=torch.int32, device=x.device)
+    else:
+        _dev(status, "status", torch.int32)
+    if rhs_values is not None:
+        _dev(rhs_values, "rhs_values")
+        rhs_id, params = RHS_ARRAY, None
+    else:
+        rhs_id, params = RHS_SIN, _capi.rhs_params(*rhs)
+    ms = ctypes.c_float(0.0)
+    rc = lib.lssvr_enhance_shared(_ptr(x), _ptr(u), ne, int(elem_offset), int(ne_global),
+                                  float(global_domain[0]), float(global_domain[1]),
+                                  float(bc[0]), float(bc[1]), int(M), int(n_colloc),
+                                  rhs_id, params, _ptr(rhs_values), _ptr(op),
+                                  _ptr(out), _ptr(status), _ptr(fail_count), _stream(stream),
+                                  ctypes.byref(ms) if profiled else None)
+    _capi.check(rc, "lssvr_enhance_shared")
+    if profiled:
+        return ms.value * 1e-3
+    return out, status
 
 
 def enhance_profiled(x, u, M, gamma, n_colloc=12, *, rhs=(POISSON_AMP, POISSON_OMEGA),

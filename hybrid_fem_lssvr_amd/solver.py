@@ -19,7 +19,9 @@ Additions over the reference (all keyword-only, defaults reproduce the reference
 ``nquad`` (scikit-fem's default 2-point rule for P1), ``mesh`` (a scikit-fem style
 mesh/basis or node array instead of ``np.linspace(a, b, num_fem_nodes)``), ``fem_solver``
 (``"bands"``: the assembled float64 tridiagonal system, as ``enforce`` + ``solve`` see it;
-``"flux"``: exact-structure prefix-scan solve).
+``"flux"``: exact-structure prefix-scan solve), ``solver``
+(``ops.SOLVER_PRIMAL`` default; ``ops.SOLVER_SHARED``: uniform meshes only, one shared operator
+applied per element).
 """
 from __future__ import annotations
 
@@ -99,6 +101,25 @@ def _rhs_mode(rhs, x_dev, n_colloc):
     return None, _to_dev(f, x_dev.device)
 
 
+def _enhance(x, u, M, gamma, n_colloc, *, global_domain, bc, solver, uniform_rtol=1e-9, **kw):
+    """ops.enhance, or -- for ``solver=ops.SOLVER_SHARED`` -- the uniform-mesh shortcut: checks that
+    every element length is within ``uniform_rtol`` of the mean, builds the shared operator with
+    the general kernel and applies it (``lssvr_enhance_shared``)."""
+    if solver != ops.SOLVER_SHARED:
+        return ops.enhance(x, u, M, gamma, n_colloc, global_domain=global_domain, bc=bc, solver=solver, **kw)
+    ne = x.numel() - 1
+    if ne < 1:
+        raise ValueError("need at least one element")
+    hs = x[1:] - x[:-1]
+    h0 = float(((x[-1] - x[0]) / ne).item())
+    dev_rel = float(((hs / h0 - 1.0).abs().max()).item())
+    if not dev_rel <= uniform_rtol:
+        raise ValueError(f"solver='shared' needs a uniform mesh: element lengths deviate by {dev_rel:.2e} "
+                         f"(> uniform_rtol = {uniform_rtol:.1e}); use the general solver")
+    op = ops.build_shared_operator(h0, M, gamma, n_colloc, device=x.device)
+    return ops.enhance_shared(x, u, op, M, n_colloc, global_domain=global_domain, bc=bc, **kw)
+
+
 class EnhancedSolution:
     """Per-element Legendre coefficients on the device plus what is needed to use
     them: ``W`` float64[ne, M] (row i = ``lssvr_functions[i].coef``), ``nodes``
@@ -170,8 +191,8 @@ def enhance_elements(mesh, nodal_values, M, gamma, *, n_colloc=12, rhs=poisson_r
         global_domain = (float(m.nodes[0]), float(m.nodes[-1]))
     pr, fv = _rhs_mode(rhs, x, n_colloc)
     kw = dict(rhs=pr) if pr is not None else dict(rhs_values=fv)
-    W, st = ops.enhance(x, u, int(M), float(gamma), int(n_colloc), global_domain=global_domain,
-                        bc=bc, solver=solver, **kw)
+    W, st = _enhance(x, u, int(M), float(gamma), int(n_colloc), global_domain=global_domain,
+                     bc=bc, solver=solver, **kw)
     return EnhancedSolution(x, W, st)
 
 
@@ -330,11 +351,11 @@ class FEMLSSVRPrimalSolver:
         u = _to_dev(self.fem_values, dev)       # the attribute is authoritative (may be user-set)
         pr, fv = _rhs_mode(self.rhs, x, self.n_colloc)
         kw = dict(rhs=pr) if pr is not None else dict(rhs_values=fv)
-        W, st = ops.enhance(x, u, int(self.lssvr_M), float(self.lssvr_gamma), int(self.n_colloc),
-                            global_domain=(float(self.global_domain[0]), float(self.global_domain[1])),
-                            bc=(main_boundary_condition_left(self.global_domain[0]),
-                                main_boundary_condition_right(self.global_domain[1])),
-                            solver=self.solver_id, **kw)
+        W, st = _enhance(x, u, int(self.lssvr_M), float(self.lssvr_gamma), int(self.n_colloc),
+                         global_domain=(float(self.global_domain[0]), float(self.global_domain[1])),
+                         bc=(main_boundary_condition_left(self.global_domain[0]),
+                             main_boundary_condition_right(self.global_domain[1])),
+                         solver=self.solver_id, **kw)
         self.enhanced = EnhancedSolution(x, W, st)
         nbad = self.enhanced.n_fallback
         if nbad:

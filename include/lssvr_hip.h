@@ -174,6 +174,30 @@ int lssvr_enhance_subset(const double* x, const double* u, int64_t ne_mesh,
                          void* stream);
 
 /*
+ * lssvr_enhance_shared -- UNIFORM meshes only; a separate, faster form of the hot path, never
+ * chosen implicitly.  On a uniform mesh every element has the same system matrix, so the
+ * coefficients are a linear map of the element's data:
+ *     W[e,:] = sum_k op[k,:] f(x_k)/scl_e^2 + op[n,:] g_l + op[n+1,:] g_r .
+ * op[(n_colloc+2)*M] (device, row-major) is built by the caller with lssvr_enhance itself on a
+ * few elements of the mesh's spacing h: rows k < n = response to rhs_values = scl^2 e_k with zero
+ * nodal values, row n / n+1 = response to (g_l, g_r) = (1,0) / (0,1) with zero rhs
+ * (hybrid_fem_lssvr_amd.ops.build_shared_operator does exactly that; gamma enters only there).
+ * Per element the abscissae, f, scl and the boundary rule of lssvr_enhance stay exact; shared
+ * is the operator (<= 1e-12 relative L2 from lssvr_enhance on uniform meshes).  M <= 16;
+ * LSSVR_RHS_SIN needs |omega x| < 3e9 (beyond: status = LSSVR_ST_FALLBACK).
+ * kernel_ms_host != NULL: blocking, returns the dispatch's own duration (measurement aid).
+ * The caller is responsible for the mesh being uniform.
+ */
+int lssvr_enhance_shared(const double* x, const double* u, int64_t ne,
+                         int64_t elem_offset, int64_t ne_global,
+                         double gxmin, double gxmax, double bc_left, double bc_right,
+                         int M, int n_colloc,
+                         int rhs_id, const double* rhs_params_host, const double* rhs_values,
+                         const double* op,
+                         double* W, int32_t* status, int32_t* fail_count, void* stream,
+                         float* kernel_ms_host);
+
+/*
  * lssvr_colloc_points -- x_k of every element exactly as `np.linspace(xmin, xmax, n)`
  * produces them (Dual.py:40): xc[e*n + k] = fl(fl(k*step)+x[e]), last = x[e+1].
  * Lets the host tabulate an arbitrary `rhs_func` for LSSVR_RHS_ARRAY.
