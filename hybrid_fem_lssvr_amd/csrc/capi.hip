@@ -52,6 +52,8 @@ int fill_enhance_args(lssvr::EnhanceArgs& a, const double* x, const double* u, i
   a.M = M;
   a.n = n_colloc;
   a.W = W;
+  static const lssvr::TrigTables trig = lssvr::make_trig_tables();
+  a.trig = trig;
   return LSSVR_OK;
 }
 

@@ -13,6 +13,7 @@
 // of the path.  Everything that depends on the element itself stays exact per element: the
 // abscissae x_k (numpy's linspace arithmetic), f(x_k) with numpy's argument rounding, scl_e,
 // the boundary values and the Dual.py:65-75 rule.  What is shared is the operator, i.e. the
+// (in-kernel f needs |omega x| < 3e9: beyond, the coefficients are NaN -> status FALLBACK)
 // rounding of t_k = off + scl x_k of the canonical element instead of each element's own:
 // <= 1e-12 relative L2 on the BASELINE meshes (tests/test_gpu_shared.py), inside north_star's
 // 1e-10 but outside this repository's 1e-13 bar for the general path -- hence a separate solver.
@@ -25,83 +26,9 @@
 
 namespace lssvr {
 
-// Polynomial coefficients of the argument-reduced sin / cos (lssvr_device.hpp) passed as kernel
-// arguments: as SGPR operands they cost no VGPRs (as hoisted literals they cost 60 and cap the
-// occupancy of this otherwise small kernel at 4 waves per SIMD).  Arguments beyond 3e9 -- where
-// the general kernel calls the library routine -- are out of range for this path: NaN, which
-// surfaces as status = LSSVR_ST_FALLBACK.
-struct TrigTables {
-  double s[10];   // -1/21! .. 1/3!
-  double c[11];   //  1/22! .. 1/2!
-};
-
-inline TrigTables make_trig_tables() {
-  TrigTables t{};
-  const double s[10] = {-1.0 / 51090942171709440000.0, 1.0 / 121645100408832000.0,
-                        -1.0 / 355687428096000.0,      1.0 / 1307674368000.0,
-                        -1.0 / 6227020800.0,           1.0 / 39916800.0,
-                        -1.0 / 362880.0,               1.0 / 5040.0,
-                        -1.0 / 120.0,                  1.0 / 6.0};
-  const double c[11] = {1.0 / 1124000727777607680000.0, -1.0 / 2432902008176640000.0,
-                        1.0 / 6402373705728000.0,       -1.0 / 20922789888000.0,
-                        1.0 / 87178291200.0,            -1.0 / 479001600.0,
-                        1.0 / 3628800.0,                -1.0 / 40320.0,
-                        1.0 / 720.0,                    -1.0 / 24.0,
-                        0.5};
-  for (int i = 0; i < 10; ++i) t.s[i] = s[i];
-  for (int i = 0; i < 11; ++i) t.c[i] = c[i];
-  return t;
-}
-
-__device__ __forceinline__ void trig_reduce(double arg, double& r, long long& ji) {
-  constexpr double kInvPi = 0.31830988618379067154;
-  constexpr double kPiHi = 3.14159265358979311600e+00;
-  constexpr double kPiLo = 1.22464679914735317723e-16;
-  const double j = rint(arg * kInvPi);
-  r = fma(-j, kPiHi, arg);
-  r = fma(-j, kPiLo, r);
-  ji = (long long)j;
-  if (!(fabs(arg) < 3.0e9)) r = __builtin_nan("");
-}
-
-__device__ __forceinline__ double sin_tab(double arg, const TrigTables& t) {
-  double r;
-  long long ji;
-  trig_reduce(arg, r, ji);
-  const double z = r * r;
-  double p = t.s[0];
-#pragma unroll
-  for (int i = 1; i < 10; ++i) p = fma(p, z, t.s[i]);
-  const double s = fma(-(r * z), p, r);
-  return (ji & 1) ? -s : s;
-}
-
-__device__ __forceinline__ void sincos_tab(double arg, double& s_out, double& c_out,
-                                           const TrigTables& t) {
-  double r;
-  long long ji;
-  trig_reduce(arg, r, ji);
-  const double z = r * r;
-  double p = t.s[0];
-#pragma unroll
-  for (int i = 1; i < 10; ++i) p = fma(p, z, t.s[i]);
-  double s = fma(-(r * z), p, r);
-  double q = t.c[0];
-#pragma unroll
-  for (int i = 1; i < 11; ++i) q = fma(q, z, t.c[i]);
-  double c = fma(-z, q, 1.0);
-  if (ji & 1) {
-    s = -s;
-    c = -c;
-  }
-  s_out = s;
-  c_out = c;
-}
-
 template <int M, int RHS>
 __global__ __launch_bounds__(kBlock) void enhance_shared_kernel(EnhanceArgs p,
-                                                                const double* __restrict__ op,
-                                                                TrigTables tt) {
+                                                                const double* __restrict__ op) {
   __shared__ double tile[kBlock * M];
   const int tid = threadIdx.x;
   const int64_t e = (int64_t)blockIdx.x * kBlock + tid;
@@ -131,7 +58,7 @@ __global__ __launch_bounds__(kBlock) void enhance_shared_kernel(EnhanceArgs p,
     if constexpr (RHS == LSSVR_RHS_SIN) {
       th0 = p.rhs_omega * a;
       dth = p.rhs_omega * step;
-      sincos_tab(th0, rs, rc, tt);
+      sincos_tab<false>(th0, rs, rc, p.trig);
       if (__all(fabs(dth) < 0.5)) {
         // short Taylor pair for the step angle: truncation 0.5^15/15! < 3e-17
         const double z = dth * dth;
@@ -151,7 +78,7 @@ __global__ __launch_bounds__(kBlock) void enhance_shared_kernel(EnhanceArgs p,
         pc = fma(pc, z, 0.5);
         cd = fma(-z, pc, 1.0);
       } else {
-        sincos_tab(dth, sd, cd, tt);
+        sincos_tab<false>(dth, sd, cd, p.trig);
       }
       kappa = p.rhs_amp * inv_scl2;
       rs *= kappa;
@@ -176,7 +103,7 @@ __global__ __launch_bounds__(kBlock) void enhance_shared_kernel(EnhanceArgs p,
           const double arg = p.rhs_omega * xk;
           const double delta = fma(-(double)k, dth, arg - th0);
           ft = fma(rc, delta, rs);
-          if (__any(!(fabs(delta) < 1.0e-7))) ft = kappa * sin_tab(arg, tt);
+          if (__any(!(fabs(delta) < 1.0e-7))) ft = kappa * sin_tab<false>(arg, p.trig);
           const double rs_next = fma(rs, cd, rc * sd);
           rc = fma(rc, cd, -(rs * sd));
           rs = rs_next;
@@ -229,10 +156,9 @@ template <int M>
 static hipError_t launch_shared(const EnhanceArgs& a, const double* op, hipStream_t s,
                                 const LaunchOpts* o) {
   const unsigned blocks = (unsigned)((a.ne + kBlock - 1) / kBlock);
-  static const TrigTables tt = make_trig_tables();
   if (a.rhs_id == LSSVR_RHS_SIN)
-    return launch(enhance_shared_kernel<M, LSSVR_RHS_SIN>, dim3(blocks), dim3(kBlock), s, o, a, op, tt);
-  return launch(enhance_shared_kernel<M, LSSVR_RHS_ARRAY>, dim3(blocks), dim3(kBlock), s, o, a, op, tt);
+    return launch(enhance_shared_kernel<M, LSSVR_RHS_SIN>, dim3(blocks), dim3(kBlock), s, o, a, op);
+  return launch(enhance_shared_kernel<M, LSSVR_RHS_ARRAY>, dim3(blocks), dim3(kBlock), s, o, a, op);
 }
 
 hipError_t enhance_shared(const EnhanceArgs& a, const double* op, hipStream_t s,

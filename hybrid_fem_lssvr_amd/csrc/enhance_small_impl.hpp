@@ -112,8 +112,8 @@ __device__ __forceinline__ void enhance_small_body(const EnhanceArgs& p, const u
       if constexpr (RHS == LSSVR_RHS_SIN) {
         th0 = p.rhs_omega * a;
         dth = p.rhs_omega * step;
-        sincos_reduced(th0, rs, rc);
-        sincos_reduced(dth, sd, cd);
+        sincos_tab(th0, rs, rc, p.trig);
+        sincos_tab(dth, sd, cd, p.trig);
         kappa = -(p.rhs_amp * inv_scl2);
         rs *= kappa;
         rc *= kappa;
@@ -126,7 +126,7 @@ __device__ __forceinline__ void enhance_small_body(const EnhanceArgs& p, const u
           const double arg = p.rhs_omega * xk;
           const double delta = fma(-(double)k, dth, arg - th0);
           phi = fma(rc, delta, rs);
-          if (__any(!(fabs(delta) < 1.0e-7))) phi = kappa * sin_reduced(arg);
+          if (__any(!(fabs(delta) < 1.0e-7))) phi = kappa * sin_tab(arg, p.trig);
           const double rs_next = fma(rs, cd, rc * sd);
           rc = fma(rc, cd, -(rs * sd));
           rs = rs_next;
@@ -261,8 +261,8 @@ __device__ __forceinline__ void enhance_small_body(const EnhanceArgs& p, const u
 }
 
 // MINW = minimum waves per SIMD the register allocator must leave room for.  1: no
-// constraint (fewest instructions: best when the launch has <= 2 waves per SIMD, e.g. 1e5
-// elements); 3: <= 168 VGPRs (a few spills, but a third resident wave: +6 % at >= 1e6 elements).
+// constraint (142 VGPRs at M = 9 with the trigonometric coefficients in SGPRs: three resident
+// waves); 4: <= 128 VGPRs for launches that can fill a fourth wave slot.
 template <int M, int RHS, bool VC, int MINW>
 __global__ __launch_bounds__(kBlock, MINW) void enhance_small_kernel(EnhanceArgs p) {
   __shared__ double tile[kBlock * M];
@@ -291,12 +291,11 @@ __global__ __launch_bounds__(kBlock) void step_small_kernel(EnhanceArgs p, P1Arg
 template <int M, int RHS, bool VC>
 static hipError_t launch_small(const EnhanceArgs& a, hipStream_t s, const LaunchOpts* o) {
   const unsigned blocks = (unsigned)((a.ne + kBlock - 1) / kBlock);
-  // more than 2 waves per SIMD on the 256-CU chip -> the occupancy-3 build pays off, but only
-  // where the kernel is within a few registers of 168 VGPRs anyway (M <= 9; at M = 12 the
-  // forced spills cost 2.3x)
+  // more than 3 waves per SIMD on the 256-CU chip -> the occupancy-4 build, but only where the
+  // kernel is within a few registers of 128 VGPRs anyway (M <= 9)
   if constexpr (M <= 9 && !VC) {
-    if (a.ne > 2 * 64 * 4 * 256)
-      return launch(enhance_small_kernel<M, RHS, VC, 3>, dim3(blocks), dim3(kBlock), s, o, a);
+    if (a.ne > 3 * 64 * 4 * 256)
+      return launch(enhance_small_kernel<M, RHS, VC, 4>, dim3(blocks), dim3(kBlock), s, o, a);
   }
   return launch(enhance_small_kernel<M, RHS, VC, 1>, dim3(blocks), dim3(kBlock), s, o, a);
 }

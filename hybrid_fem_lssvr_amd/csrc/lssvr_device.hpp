@@ -40,6 +40,11 @@ __device__ __forceinline__ double linspace_at(double a, double b, double delta, 
 // ---------------------------------------------------------------------------
 // sin for the in-kernel right-hand side
 // ---------------------------------------------------------------------------
+// |arg| >= 3e9: the library routines (Payne-Hanek reduction), kept OUT of line -- inlined they
+// raise the register allocation of every kernel that might take this once-in-never branch.
+__device__ __attribute__((noinline)) static double sin_huge(double arg) { return sin(arg); }
+__device__ __attribute__((noinline)) static double cos_huge(double arg) { return cos(arg); }
+
 // sin(arg) for |arg| < 2^30*pi: arg = j*pi + r, |r| <= pi/2, two-term FMA
 // reduction, then the odd Taylor polynomial through r^21 (truncation
 // (pi/2)^23/23! = 1.3e-18).  Larger arguments go to the ocml routine.
@@ -47,7 +52,7 @@ __device__ __forceinline__ double sin_reduced(double arg) {
   constexpr double kInvPi = 0.31830988618379067154;
   constexpr double kPiHi = 3.14159265358979311600e+00;
   constexpr double kPiLo = 1.22464679914735317723e-16;
-  if (!(fabs(arg) < 3.0e9)) return sin(arg);
+  if (!(fabs(arg) < 3.0e9)) return sin_huge(arg);
   const double j = rint(arg * kInvPi);
   double r = fma(-j, kPiHi, arg);
   r = fma(-j, kPiLo, r);
@@ -76,8 +81,8 @@ __device__ __forceinline__ void sincos_reduced(double arg, double& s_out, double
   constexpr double kPiHi = 3.14159265358979311600e+00;
   constexpr double kPiLo = 1.22464679914735317723e-16;
   if (!(fabs(arg) < 3.0e9)) {
-    s_out = sin(arg);
-    c_out = cos(arg);
+    s_out = sin_huge(arg);
+    c_out = cos_huge(arg);
     return;
   }
   const double j = rint(arg * kInvPi);
@@ -106,6 +111,94 @@ __device__ __forceinline__ void sincos_reduced(double arg, double& s_out, double
   q = fma(q, z, 1.0 / 720.0);                           //  1/6!
   q = fma(q, z, -1.0 / 24.0);                           // -1/4!
   q = fma(q, z, 0.5);                                   //  1/2!   (sign folded below)
+  double c = fma(-z, q, 1.0);
+  const long long ji = (long long)j;
+  if (ji & 1) {
+    s = -s;
+    c = -c;
+  }
+  s_out = s;
+  c_out = c;
+}
+
+// ---------------------------------------------------------------------------
+// The same sin / sincos with the polynomial coefficients read from a table that travels in
+// the kernel arguments (EnhanceArgs::trig): uniform loads -> SGPR operands.  As literals the
+// 21 coefficients are hoisted into 42 VGPRs for the whole kernel, which costs the
+// lane-per-element kernels a resident wave per SIMD.
+// ---------------------------------------------------------------------------
+struct TrigTables {
+  double s[10];   // -1/21! .. 1/3!   (sin_reduced's literals, same order)
+  double c[11];   //  1/22! .. 1/2!   (sincos_reduced's)
+};
+
+inline TrigTables make_trig_tables() {
+  TrigTables t{};
+  const double s[10] = {-1.0 / 51090942171709440000.0, 1.0 / 121645100408832000.0,
+                        -1.0 / 355687428096000.0,      1.0 / 1307674368000.0,
+                        -1.0 / 6227020800.0,           1.0 / 39916800.0,
+                        -1.0 / 362880.0,               1.0 / 5040.0,
+                        -1.0 / 120.0,                  1.0 / 6.0};
+  const double c[11] = {1.0 / 1124000727777607680000.0, -1.0 / 2432902008176640000.0,
+                        1.0 / 6402373705728000.0,       -1.0 / 20922789888000.0,
+                        1.0 / 87178291200.0,            -1.0 / 479001600.0,
+                        1.0 / 3628800.0,                -1.0 / 40320.0,
+                        1.0 / 720.0,                    -1.0 / 24.0,
+                        0.5};
+  for (int i = 0; i < 10; ++i) t.s[i] = s[i];
+  for (int i = 0; i < 11; ++i) t.c[i] = c[i];
+  return t;
+}
+
+// HUGE = false: arguments beyond 3e9 give NaN instead of the library call (the call, even out
+// of line, costs the caller ~16 VGPRs; enhance_shared.hip documents the restriction).
+template <bool HUGE = true>
+__device__ __forceinline__ double sin_tab(double arg, const TrigTables& t) {
+  constexpr double kInvPi = 0.31830988618379067154;
+  constexpr double kPiHi = 3.14159265358979311600e+00;
+  constexpr double kPiLo = 1.22464679914735317723e-16;
+  if (!(fabs(arg) < 3.0e9)) {
+    if constexpr (HUGE) return sin_huge(arg);
+    else return __builtin_nan("");
+  }
+  const double j = rint(arg * kInvPi);
+  double r = fma(-j, kPiHi, arg);
+  r = fma(-j, kPiLo, r);
+  const double z = r * r;
+  double p = t.s[0];
+#pragma unroll
+  for (int i = 1; i < 10; ++i) p = fma(p, z, t.s[i]);
+  const double s = fma(-(r * z), p, r);
+  const long long ji = (long long)j;
+  return (ji & 1) ? -s : s;
+}
+
+template <bool HUGE = true>
+__device__ __forceinline__ void sincos_tab(double arg, double& s_out, double& c_out,
+                                           const TrigTables& t) {
+  constexpr double kInvPi = 0.31830988618379067154;
+  constexpr double kPiHi = 3.14159265358979311600e+00;
+  constexpr double kPiLo = 1.22464679914735317723e-16;
+  if (!(fabs(arg) < 3.0e9)) {
+    if constexpr (HUGE) {
+      s_out = sin_huge(arg);
+      c_out = cos_huge(arg);
+    } else {
+      s_out = c_out = __builtin_nan("");
+    }
+    return;
+  }
+  const double j = rint(arg * kInvPi);
+  double r = fma(-j, kPiHi, arg);
+  r = fma(-j, kPiLo, r);
+  const double z = r * r;
+  double p = t.s[0];
+#pragma unroll
+  for (int i = 1; i < 10; ++i) p = fma(p, z, t.s[i]);
+  double s = fma(-(r * z), p, r);
+  double q = t.c[0];
+#pragma unroll
+  for (int i = 1; i < 11; ++i) q = fma(q, z, t.c[i]);
   double c = fma(-z, q, 1.0);
   const long long ji = (long long)j;
   if (ji & 1) {

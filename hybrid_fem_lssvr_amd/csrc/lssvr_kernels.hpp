@@ -4,6 +4,7 @@
 #include <hip/hip_ext.h>
 #include <stdint.h>
 #include "../../include/lssvr_hip.h"
+#include "lssvr_device.hpp"
 
 namespace lssvr {
 
@@ -32,6 +33,7 @@ struct EnhanceArgs {
   double* W;
   int32_t* status;
   int32_t* fail_count;
+  TrigTables trig;          // sin / cos polynomial coefficients (SGPR operands), set by capi.hip
 };
 
 // Optional per-launch profiling: when both events are set the kernel goes through
