@@ -359,6 +359,35 @@ def main():
                   "value": nn * args.steps / tn, "ms_per_step": tn / args.steps * 1e3,
                   "fallback_elements": int(pl.status.sum().item())}
 
+    # the same K steps issued round-robin on two HIP streams with separate output buffers: at
+    # 1e5 elements one launch fills only ~60 % of the chip's wave slots, so independent batches
+    # overlap.  Reported beside `value` (which stays the strictly sequential single-stream rate).
+    pipelined = None
+    if world == 1 and rank == 0:
+        try:
+            nstream = 2
+            streams = [torch.cuda.Stream(device=dev) for _ in range(nstream)]
+            Wp = [torch.empty((ne_loc, M), dtype=torch.float64, device=dev) for _ in range(nstream)]
+            stp = [torch.empty(ne_loc, dtype=torch.int32, device=dev) for _ in range(nstream)]
+            bp = [ops.p1_assemble(x, 2) for _ in range(nstream)]
+            pls = [ops.StepPlan(x, u, M, GAMMA, n, elem_offset=s0, ne_global=ne_glob, global_domain=gd,
+                                bands=bp[k], out=Wp[k], status=stp[k]) for k in range(nstream)]
+            torch.cuda.synchronize()
+            for i in range(args.warmup):
+                pls[i % nstream].launch(streams[i % nstream].cuda_stream)
+            torch.cuda.synchronize()
+            tp = time.perf_counter()
+            for i in range(args.steps):
+                pls[i % nstream].launch(streams[i % nstream].cuda_stream)
+            torch.cuda.synchronize()
+            tp = time.perf_counter() - tp
+            pipelined = {"what": "same K steps, round-robin on %d streams, separate W buffers" % nstream,
+                         "streams": nstream, "value": ne_loc * args.steps / tp, "unit": "elements/s",
+                         "ms_per_step": tp / args.steps * 1e3,
+                         "results_equal": bool(torch.equal(Wp[0], W[:ne_loc]) and torch.equal(Wp[1], W[:ne_loc]))}
+        except Exception as exc:  # pragma: no cover
+            pipelined = {"error": repr(exc)}
+
     # the uniform-mesh shortcut (lssvr_enhance_shared; SURVEY.md 8(d): "reported as a separate line
     # if built"): one shared operator applied per element.  Never part of `value`; its own
     # roofline is HBM (88 B per element against ~8 TB/s).
@@ -541,6 +570,8 @@ def main():
             out["narrow_domain"] = narrow
         if shared is not None:
             out["shared_operator"] = shared
+        if pipelined is not None:
+            out["pipelined"] = pipelined
         if accuracy is not None:
             out["accuracy"] = accuracy
         if cpu_res is not None:
