@@ -183,7 +183,8 @@ int lssvr_enhance_subset(const double* x, const double* u, int64_t ne_mesh,
  * nodal values, row n / n+1 = response to (g_l, g_r) = (1,0) / (0,1) with zero rhs
  * (hybrid_fem_lssvr_amd.ops.build_shared_operator does exactly that; gamma enters only there).
  * Per element the abscissae, f, scl and the boundary rule of lssvr_enhance stay exact; shared
- * is the operator (<= 1e-12 relative L2 from lssvr_enhance on uniform meshes).  M <= 16;
+ * is the operator: relative L2 distance from lssvr_enhance ~ (|x|/h) * 2e-16 (1e-11 at 1e5
+ * elements of h = 1/12).  M <= 16;
  * LSSVR_RHS_SIN needs |omega x| < 3e9 (beyond: status = LSSVR_ST_FALLBACK).
  * kernel_ms_host != NULL: blocking, returns the dispatch's own duration (measurement aid).
  * The caller is responsible for the mesh being uniform.
