@@ -20,11 +20,14 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, ne, M, n, q):
+def _worker(rank, world, port, ne, M, n, q, backend="gloo"):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda:0"))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from hybrid_fem_lssvr_amd.distributed import ShardPlan, solve_sharded
         dev = torch.device("cuda:0")
@@ -73,3 +76,22 @@ def test_sharded_solve_matches_single_rank(dev, world):
         # through those last-bit differences in the nodal values
         assert np.max(np.abs(Wg - W_ref)) <= 1e-13
     assert np.array_equal(got[0][1], got[world - 1][1])
+
+
+def test_sharded_pipeline_over_rccl_single_rank(dev):
+    """The same pipeline with backend "nccl" (= RCCL) and ONE rank: what a one-GPU box can
+    exercise of the production backend -- communicator bring-up, the 24-byte all-gather of the
+    flux aggregates and the chunk-overlapped all-gather of W on a side stream."""
+    import hybrid_fem_lssvr_amd as pkg
+    ne, M, n = 10001, 9, 16
+    ref = pkg.FEMLSSVRPrimalSolver(ne + 1, lssvr_M=M, lssvr_gamma=1e4, n_colloc=n, fem_solver="flux")
+    ref.solve()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker, args=(0, 1, _free_port(), ne, M, n, q, "nccl"))
+    p.start()
+    r, u, Wg, nbad = q.get(timeout=300)
+    p.join(120)
+    assert p.exitcode == 0 and nbad == 0
+    assert np.max(np.abs(u - ref.fem_values)) <= 1e-14
+    assert np.max(np.abs(Wg - ref.enhanced.W.cpu().numpy())) <= 1e-13
