@@ -2,7 +2,7 @@
 // both end dofs -- `enforce(A, b, D=basis.get_dofs())` + `solve(A, b)`
 // (Dual.py:129-130).  SURVEY.md section 8(f) "next-1".
 //
-// Algorithm: recursive substructuring (static condensation).  Every kLc-th
+// Algorithm: recursive substructuring (static condensation).  Every kLc-th (8th or 32nd)
 // unknown is a separator; one thread condenses the kLc-1 unknowns between two
 // separators onto them (two O(1)-state sweeps, nothing stored), the separators
 // form a tridiagonal system kLc times smaller, which is solved the same way
@@ -14,8 +14,13 @@
 
 namespace lssvr {
 
-constexpr int kLc = 32;
+// Chunk length per level: 32 at large sizes (fewest levels, half the workspace), 8 below ~4e6
+// unknowns, where a level of 32-chunks has few threads (1e5 unknowns = 49 waves on 1024
+// SIMDs).  Each row costs ONE division (1/den) and three multiplications in every sweep --
+// with three divisions per row the sweeps were bound by the FP64 division chain: 101 -> 55 us
+// at 1e5 unknowns, 177 -> 91 us at 1e6, 1.4 ms either way at 1e7 (bandwidth / L1 bound).
 constexpr int kBase = 512;
+static inline int chunk_for(int64_t m) { return m <= (int64_t(1) << 22) ? 8 : 32; }
 
 // row i: lo[i] x[i-1] + d[i] x[i] + up[i] x[i+1] = r[i] - [i==0] bl[0]*u0 - [i==m-1] br[0]*u1
 struct TriSys {
@@ -72,6 +77,7 @@ __device__ __forceinline__ void load_rows(const TriSys& s, int64_t i0, int64_t b
   }
 }
 
+template <int kLc>
 __global__ __launch_bounds__(kBlock) void tri_condense_kernel(TriSys s, int64_t nc,
                                                                ChunkEnds* __restrict__ ends) {
   const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -88,23 +94,24 @@ __global__ __launch_bounds__(kBlock) void tri_condense_kernel(TriSys s, int64_t 
       for (int t = 0; t < kBatch; ++t) {
         const int64_t i = i0 + t;
         if (i < e) {
+          // one division per row (1/den), three multiplications
           if (i == b) {
-            den = rb.d[t];
-            y = rb.r[t] / den;
-            v = -rb.lo[t] / den;
+            den = 1.0 / rb.d[t];
+            y = rb.r[t] * den;
+            v = -rb.lo[t] * den;
           } else {
             const double l = rb.lo[t];
-            den = rb.d[t] - l * cp;
-            y = (rb.r[t] - l * y) / den;
-            v = (-l * v) / den;
+            den = 1.0 / (rb.d[t] - l * cp);
+            y = (rb.r[t] - l * y) * den;
+            v = (-l * v) * den;
           }
-          cp = rb.up[t] / den;
+          cp = rb.up[t] * den;
         }
       }
     }
     c.yL = y;
     c.vL = v;
-    c.wL = -cp;               // rhs -up[e-1] e_last  ->  -up[e-1]/den_last
+    c.wL = -cp;               // rhs -up[e-1] e_last  ->  -up[e-1]/den_last  (den holds 1/den)
   }
   {  // upward sweep -> values at the first interior unknown
     double den = 1.0, bp = 0.0, y = 0.0, w = 0.0;
@@ -116,16 +123,16 @@ __global__ __launch_bounds__(kBlock) void tri_condense_kernel(TriSys s, int64_t 
         const int64_t i = i1 - kBatch + t;
         if (i >= b) {
           if (i == e - 1) {
-            den = rb.d[t];
-            y = rb.r[t] / den;
-            w = -rb.up[t] / den;
+            den = 1.0 / rb.d[t];
+            y = rb.r[t] * den;
+            w = -rb.up[t] * den;
           } else {
             const double u = rb.up[t];
-            den = rb.d[t] - u * bp;
-            y = (rb.r[t] - u * y) / den;
-            w = (-u * w) / den;
+            den = 1.0 / (rb.d[t] - u * bp);
+            y = (rb.r[t] - u * y) * den;
+            w = (-u * w) * den;
           }
-          bp = rb.lo[t] / den;
+          bp = rb.lo[t] * den;
         }
       }
     }
@@ -137,6 +144,7 @@ __global__ __launch_bounds__(kBlock) void tri_condense_kernel(TriSys s, int64_t 
 }
 
 // separator j sits at p = j*kLc + kLc-1, between chunk j (left) and chunk j+1 (right)
+template <int kLc>
 __global__ __launch_bounds__(kBlock) void tri_reduce_kernel(TriSys s, int64_t ns, int64_t nc,
                                                              const ChunkEnds* __restrict__ ends,
                                                              double* __restrict__ LO,
@@ -166,6 +174,7 @@ __global__ __launch_bounds__(kBlock) void tri_reduce_kernel(TriSys s, int64_t ns
 
 // re-solve every chunk with its separator values known; x (length m) receives the
 // whole level's solution.  cp: scratch of length m.
+template <int kLc>
 __global__ __launch_bounds__(kBlock) void tri_expand_kernel(TriSys s, int64_t ns, int64_t nc,
                                                              const double* __restrict__ X,
                                                              double* __restrict__ x,
@@ -194,14 +203,14 @@ __global__ __launch_bounds__(kBlock) void tri_expand_kernel(TriSys s, int64_t ns
           if (i == b) ri -= rb.lo[t] * xl;
           if (i == e - 1) ri -= rb.up[t] * xr;
           if (i == b) {
-            den = rb.d[t];
-            y = ri / den;
+            den = 1.0 / rb.d[t];
+            y = ri * den;
           } else {
             const double l = rb.lo[t];
-            den = rb.d[t] - l * c;
-            y = (ri - l * y) / den;
+            den = 1.0 / (rb.d[t] - l * c);
+            y = (ri - l * y) * den;
           }
-          c = rb.up[t] / den;
+          c = rb.up[t] * den;
         }
         cc[g * kBatch + t] = c;
         yy[g * kBatch + t] = y;
@@ -279,6 +288,7 @@ __global__ void tri_ends_kernel(double* u, int64_t ne, double u0, double u1) {
 static int64_t level_doubles(int64_t m) {
   int64_t tot = 0;
   while (m > kBase) {
+    const int kLc = chunk_for(m);
     const int64_t nc = (m + kLc - 1) / kLc, ns = m / kLc;
     tot += m + 6 * nc + 5 * ns + 16;
     m = ns;
@@ -291,12 +301,10 @@ int64_t tridiag_work_bytes(int64_t ne) {
   return 8 * level_doubles(m) + 256;
 }
 
-static hipError_t solve_level(const TriSys& s, double* x, double* work, hipStream_t st) {
-  if (s.m <= 0) return hipSuccess;
-  if (s.m <= kBase) {
-    hipLaunchKernelGGL(tri_base_kernel, dim3(1), dim3((unsigned)kBase), 0, st, s, x, work);
-    return hipGetLastError();
-  }
+static hipError_t solve_level(const TriSys& s, double* x, double* work, hipStream_t st);
+
+template <int kLc>
+static hipError_t solve_level_chunked(const TriSys& s, double* x, double* work, hipStream_t st) {
   const int64_t nc = (s.m + kLc - 1) / kLc, ns = s.m / kLc;
   double* cp = work;
   ChunkEnds* ends = reinterpret_cast<ChunkEnds*>(cp + s.m);
@@ -308,13 +316,23 @@ static hipError_t solve_level(const TriSys& s, double* x, double* work, hipStrea
   double* next = X + ns + 16;
   const unsigned gc = (unsigned)((nc + kBlock - 1) / kBlock);
   const unsigned gs = (unsigned)((ns + kBlock - 1) / kBlock);
-  hipLaunchKernelGGL(tri_condense_kernel, dim3(gc), dim3(kBlock), 0, st, s, nc, ends);
-  hipLaunchKernelGGL(tri_reduce_kernel, dim3(gs), dim3(kBlock), 0, st, s, ns, nc, ends, LO, D, UP, R);
+  hipLaunchKernelGGL(tri_condense_kernel<kLc>, dim3(gc), dim3(kBlock), 0, st, s, nc, ends);
+  hipLaunchKernelGGL(tri_reduce_kernel<kLc>, dim3(gs), dim3(kBlock), 0, st, s, ns, nc, ends, LO, D, UP, R);
   TriSys r{LO, D, UP, R, nullptr, nullptr, 0.0, 0.0, ns};
   hipError_t err = solve_level(r, X, next, st);
   if (err != hipSuccess) return err;
-  hipLaunchKernelGGL(tri_expand_kernel, dim3(gc), dim3(kBlock), 0, st, s, ns, nc, X, x, cp);
+  hipLaunchKernelGGL(tri_expand_kernel<kLc>, dim3(gc), dim3(kBlock), 0, st, s, ns, nc, X, x, cp);
   return hipGetLastError();
+}
+
+static hipError_t solve_level(const TriSys& s, double* x, double* work, hipStream_t st) {
+  if (s.m <= 0) return hipSuccess;
+  if (s.m <= kBase) {
+    hipLaunchKernelGGL(tri_base_kernel, dim3(1), dim3((unsigned)kBase), 0, st, s, x, work);
+    return hipGetLastError();
+  }
+  return chunk_for(s.m) == 8 ? solve_level_chunked<8>(s, x, work, st)
+                             : solve_level_chunked<32>(s, x, work, st);
 }
 
 hipError_t tridiag_dirichlet_solve(const double* diag, const double* off, const double* load,
