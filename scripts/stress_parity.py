@@ -6,6 +6,7 @@ from hybrid_fem_lssvr_amd import ops
 from oracle import lssvr_oracle as orc, closed_form_mp as cf
 
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+solver = int(sys.argv[3]) if len(sys.argv) > 3 else ops.SOLVER_PRIMAL      # 2 = force the wave / MFMA mapping
 dev = torch.device("cuda:0")
 worst = []
 for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 120):
@@ -22,7 +23,8 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 120):
     gd = (nodes[0], nodes[-1])
     x, u = torch.as_tensor(nodes, device=dev), torch.as_tensor(values, device=dev)
     try:
-        W, st = ops.enhance(x, u, M, gamma, n, global_domain=gd)
+        W, st = ops.enhance(x, u, M, gamma, n, global_domain=gd,
+                            solver=solver if n >= M - 2 else ops.SOLVER_PRIMAL)
     except Exception as exc:
         print(f"M={M} n={n}: {str(exc)[:90]}")
         continue
@@ -30,7 +32,7 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 120):
     sel = [0, 5, 11]
     tr = cf.truth_all(nodes, values, M, gamma, n, orc.poisson_rhs, gd, sel)
     err = orc.rel_l2_coef(W[sel], tr)
-    route = "dual" if n < M - 2 else ("lane" if M <= 14 else "wave")
+    route = "dual" if n < M - 2 else ("lane" if (M <= 22 and solver == ops.SOLVER_PRIMAL) else "wave")
     e = float(np.nanmax(err)) if np.all(st[sel] == 0) else float("nan")
     worst.append((e, M, n, gamma, h, x0, route, int(st.sum())))
 worst.sort(key=lambda t: (-(t[0] if t[0] == t[0] else 1e9)))
