@@ -29,6 +29,14 @@
 
 namespace lssvr {
 
+// LDS per wave: the 64 x M output tile, or (tabulated inputs) kStageK points of 64 rows per
+// array at pitch kStageK + 1 -- whichever is larger; the two uses never overlap in time.
+constexpr int kStageK = 8;
+constexpr int kStageArr = 64 * (kStageK + 1);
+template <int M, int RHS, bool VC>
+constexpr int kSmallTilePerWave =
+    (RHS == LSSVR_RHS_ARRAY && (VC ? 3 : 1) * kStageArr > 64 * M) ? (VC ? 3 : 1) * kStageArr : 64 * M;
+
 template <int M, int RHS, bool VC>
 __device__ __forceinline__ void enhance_small_body(const EnhanceArgs& p, const unsigned block,
                                                    double* __restrict__ tile) {
@@ -43,8 +51,13 @@ __device__ __forceinline__ void enhance_small_body(const EnhanceArgs& p, const u
   for (int i = 0; i < M; ++i) w[i] = 0.0;
 
   const bool scattered = p.elem_ids != nullptr || (p.ldw != 0 && p.ldw != M);
-  if (e < p.ne) {
-    const int64_t id = p.elem_ids ? p.elem_ids[e] : e;      // mesh index of this element
+  // Every lane runs the body (lanes past the end of the last wave on a duplicate of the last
+  // element, their stores masked): the tabulated inputs are loaded cooperatively by the wave.
+  const bool live = e < p.ne;
+  const int64_t ec = live ? e : p.ne - 1;                   // position in this launch
+  const int lane = tid & 63;
+  {
+    const int64_t id = p.elem_ids ? p.elem_ids[ec] : ec;    // mesh index of this element
     const double a = p.x[id];
     const double b = p.x[id + 1];
     const int64_t eg = id + p.elem_offset;
@@ -118,7 +131,36 @@ __device__ __forceinline__ void enhance_small_body(const EnhanceArgs& p, const u
         rs *= kappa;
         rc *= kappa;
       }
+      // Tabulated inputs (rhs_values, a_values, da_values: [element][point], a row per element):
+      // a lane walking its own row touches 64 different cache lines per load instruction (6 %
+      // of each used) and thrashes the L1 -- measured 9x slower than the in-kernel rhs.  The
+      // wave loads kStageK points of its 64 rows at a time with consecutive lanes on consecutive
+      // doubles (full 64-byte runs of every row) into LDS, row pitch kStageK + 1 (conflict-free
+      // when every lane then reads its own row).
+      [[maybe_unused]] double* const stg = tile + (tid >> 6) * kSmallTilePerWave<M, RHS, VC>;
+      [[maybe_unused]] const int64_t e0 = (int64_t)block * kBlock + (tid & ~63);
       for (int k = 0; k < n; ++k) {
+        if constexpr (RHS == LSSVR_RHS_ARRAY) {
+          if ((k & (kStageK - 1)) == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < kStageK; ++i) {
+              const int idx = i * 64 + lane;
+              const int row = idx / kStageK, kk = idx % kStageK;
+              const int64_t er = e0 + row;
+              const bool in = (er < p.ne) && (k + kk < n);
+              const int64_t g = in ? er * n + (k + kk) : 0;
+              stg[row * (kStageK + 1) + kk] = in ? p.rhs_values[g] : 0.0;
+              if constexpr (VC) {
+                stg[kStageArr + row * (kStageK + 1) + kk] = in ? p.a_values[g] : 0.0;
+                stg[2 * kStageArr + row * (kStageK + 1) + kk] = in ? p.da_values[g] : 0.0;
+              }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+          }
+        }
         const double xk = linspace_at(a, b, dm.oldlen, step, k, n);
         const double tk = dm.off + dm.scl * xk;
         double fk = 0.0, phi;
@@ -131,15 +173,15 @@ __device__ __forceinline__ void enhance_small_body(const EnhanceArgs& p, const u
           rc = fma(rc, cd, -(rs * sd));
           rs = rs_next;
         } else {
-          fk = p.rhs_values[e * n + k];
+          fk = stg[lane * (kStageK + 1) + (k & (kStageK - 1))];
           phi = -(fk * inv_scl2);
         }
         double rho[MR];
         if constexpr (VC) legendre_d2<MR>(tk, rho);
         else legendre_d2_scaled<MR>(tk, rho);
         if constexpr (VC) {
-          const double ak = p.a_values[e * n + k];
-          const double bk = p.da_values[e * n + k] / dm.scl;
+          const double ak = stg[kStageArr + lane * (kStageK + 1) + (k & (kStageK - 1))];
+          const double bk = stg[2 * kStageArr + lane * (kStageK + 1) + (k & (kStageK - 1))] / dm.scl;
           double r1[MR + 1];
           legendre_d1<MR + 1>(tk, r1);        // r1[m] = L'_{m+1}; need L'_{j+2} = r1[j+1]
 #pragma unroll
@@ -229,10 +271,10 @@ __device__ __forceinline__ void enhance_small_body(const EnhanceArgs& p, const u
       for (int i = 0; i < M; ++i) w[i] = 0.0;
       w[0] = 0.5 * (gl + gr);
       w[1] = 0.5 * (gr - gl);
-      if (p.fail_count) atomicAdd(p.fail_count, 1);
+      if (live && p.fail_count) atomicAdd(p.fail_count, 1);
     }
-    if (p.status) p.status[id] = st;
-    if (scattered) {
+    if (live && p.status) p.status[id] = st;
+    if (live && scattered) {
       // heterogeneous launch: rows go to the mesh index, ldw apart (direct stores)
       double* const Wrow = p.W + id * (p.ldw ? p.ldw : (int64_t)M);
 #pragma unroll
@@ -244,8 +286,9 @@ __device__ __forceinline__ void enhance_small_body(const EnhanceArgs& p, const u
   // --- coalesced store: each wave transposes its own 64 x M tile through LDS --------
   // (wave-private, so no workgroup barrier: a wave that finishes early stores early;
   // LDS operations of one wave execute in order)
-  const int lane = tid & 63;
-  double* const wt = tile + (tid >> 6) * (64 * M);
+  double* const wt = tile + (tid >> 6) * kSmallTilePerWave<M, RHS, VC>;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // (the staging reads are done)
+  __builtin_amdgcn_wave_barrier();
 #pragma unroll
   for (int i = 0; i < M; ++i) wt[lane * M + i] = w[i];
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -265,7 +308,7 @@ __device__ __forceinline__ void enhance_small_body(const EnhanceArgs& p, const u
 // waves); 4: <= 128 VGPRs for launches that can fill a fourth wave slot.
 template <int M, int RHS, bool VC, int MINW>
 __global__ __launch_bounds__(kBlock, MINW) void enhance_small_kernel(EnhanceArgs p) {
-  __shared__ double tile[kBlock * M];
+  __shared__ double tile[(kBlock / 64) * kSmallTilePerWave<M, RHS, VC>];
   enhance_small_body<M, RHS, VC>(p, blockIdx.x, tile);
 }
 
