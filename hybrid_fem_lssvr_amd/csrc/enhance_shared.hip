@@ -27,10 +27,13 @@
 
 namespace lssvr {
 
+template <int M>
+constexpr int kSharedTilePerWave = (64 * 9 > 64 * M) ? 64 * 9 : 64 * M;   // output tile / rhs staging
+
 template <int M, int RHS>
 __global__ __launch_bounds__(kBlock) void enhance_shared_kernel(EnhanceArgs p,
                                                                 const double* __restrict__ op) {
-  __shared__ double tile[kBlock * M];
+  __shared__ double tile[(kBlock / 64) * kSharedTilePerWave<M>];
   const int tid = threadIdx.x;
   const int64_t e = (int64_t)blockIdx.x * kBlock + tid;
   double w[M];
@@ -38,12 +41,17 @@ __global__ __launch_bounds__(kBlock) void enhance_shared_kernel(EnhanceArgs p,
 #pragma unroll
   for (int i = 0; i < M; ++i) w[i] = 0.0;
 
-  if (e < p.ne) {
-    const double a = p.x[e];
-    const double b = p.x[e + 1];
-    const int64_t eg = e + p.elem_offset;
-    const double gl = (eg == 0 && a == p.gxmin) ? p.bc_left : p.u[e];            // Dual.py:65-75
-    const double gr = (eg == p.ne_global - 1 && b == p.gxmax) ? p.bc_right : p.u[e + 1];
+  // every lane runs the body (the tail of the last wave on a duplicate of the last element,
+  // stores masked): a tabulated rhs is loaded cooperatively by the wave
+  const bool live = e < p.ne;
+  const int64_t ec = live ? e : p.ne - 1;
+  const int lane = tid & 63;
+  {
+    const double a = p.x[ec];
+    const double b = p.x[ec + 1];
+    const int64_t eg = ec + p.elem_offset;
+    const double gl = (eg == 0 && a == p.gxmin) ? p.bc_left : p.u[ec];           // Dual.py:65-75
+    const double gr = (eg == p.ne_global - 1 && b == p.gxmax) ? p.bc_right : p.u[ec + 1];
     const int n = p.n;
     const double oldlen = b - a;
     const double step = oldlen / (double)(n - 1);             // numpy's linspace step (exact division)
@@ -97,8 +105,29 @@ __global__ __launch_bounds__(kBlock) void enhance_shared_kernel(EnhanceArgs p,
         for (int i = 0; i < M; ++i) w[i] = fma(Pk[i], ft, w[i]);
       }
     } else {
+      // tabulated rhs: 8 points of the wave's 64 rows at a time through LDS, consecutive lanes
+      // on consecutive doubles (enhance_small_impl.hpp; the area is the output tile's)
+      constexpr int kK = 8;
+      [[maybe_unused]] double* const stg = tile + (tid >> 6) * kSharedTilePerWave<M>;
+      [[maybe_unused]] const int64_t e0 = (int64_t)blockIdx.x * kBlock + (tid & ~63);
       for (int k = 0; k < n; ++k) {
         double ft;
+        if constexpr (RHS == LSSVR_RHS_ARRAY) {
+          if ((k & (kK - 1)) == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < kK; ++i) {
+              const int idx = i * 64 + lane;
+              const int row = idx / kK, kk = idx % kK;
+              const int64_t er = e0 + row;
+              const bool in = (er < p.ne) && (k + kk < n);
+              stg[row * (kK + 1) + kk] = in ? p.rhs_values[er * n + (k + kk)] : 0.0;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+          }
+        }
         if constexpr (RHS == LSSVR_RHS_SIN) {
           const double xk = linspace_at(a, b, oldlen, step, k, n);
           const double arg = p.rhs_omega * xk;
@@ -109,7 +138,7 @@ __global__ __launch_bounds__(kBlock) void enhance_shared_kernel(EnhanceArgs p,
           rc = fma(rc, cd, -(rs * sd));
           rs = rs_next;
         } else {
-          ft = p.rhs_values[e * n + k] * inv_scl2;
+          ft = stg[lane * (kK + 1) + (k & (kK - 1))] * inv_scl2;
         }
         const double* __restrict__ Pk = op + (int64_t)k * M;
 #pragma unroll
@@ -132,14 +161,15 @@ __global__ __launch_bounds__(kBlock) void enhance_shared_kernel(EnhanceArgs p,
       for (int i = 0; i < M; ++i) w[i] = 0.0;
       w[0] = 0.5 * (gl + gr);
       if constexpr (M > 1) w[1] = 0.5 * (gr - gl);
-      if (p.fail_count) atomicAdd(p.fail_count, 1);
+      if (live && p.fail_count) atomicAdd(p.fail_count, 1);
     }
-    if (p.status) p.status[e] = st;
+    if (live && p.status) p.status[e] = st;
   }
 
   // coalesced store: each wave transposes its own 64 x M tile through wave-private LDS
-  const int lane = tid & 63;
-  double* const wt = tile + (tid >> 6) * (64 * M);
+  double* const wt = tile + (tid >> 6) * kSharedTilePerWave<M>;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // (the staging reads are done)
+  __builtin_amdgcn_wave_barrier();
 #pragma unroll
   for (int i = 0; i < M; ++i) wt[lane * M + i] = w[i];
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
