@@ -101,7 +101,7 @@ __device__ __forceinline__ double sin_reduced_tab(double arg, const double* __re
 
 
 // ---- f64 MFMA in 4x4x4 blocks ------------------------------------------------------------
-// Measured on gfx950 (variants/mfma_probe.cpp): v_mfma_f64_4x4x4_4b_f64 (four 4x4x4
+// Measured on gfx950 (scripts/probes/mfma_probe.cpp): v_mfma_f64_4x4x4_4b_f64 (four 4x4x4
 // blocks, 256 FMAs) takes 8.2 ns per SIMD, v_mfma_f64_16x16x4_f64 (1024 FMAs) 42 ns -- 28 % more
 // per FMA -- and both share the FP64 vector pipe.  Operand layout (probed with one-hot inputs):
 //   A: lane 16 k + 4 blk + i = A_blk[i][k]   B: lane 16 k + 4 blk + j = B_blk[k][j]
