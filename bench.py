@@ -588,6 +588,9 @@ def main():
                 pass
         try:
             out["roofline"]["fp64_fma_probe_tflops"] = round(ops.fp64_probe(8192, 4096, False), 2)
+            if M > 22:
+                out["roofline"]["fp64_mfma_4x4x4_probe_tflops"] = round(ops.fp64_probe(8192, 2048, 3), 2)
+                out["roofline"]["fp64_mfma_16x16x4_probe_tflops"] = round(ops.fp64_probe(8192, 1024, 1), 2)
         except Exception as exc:  # pragma: no cover
             out["roofline"]["fp64_fma_probe_tflops"] = "failed: %s" % exc
         if stages is not None:

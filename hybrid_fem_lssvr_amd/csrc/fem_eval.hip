@@ -266,6 +266,24 @@ __global__ __launch_bounds__(kBlock) void fp64_mfma_probe_kernel(double* out, in
   out[tid] = (c0[0] + c1[1]) + (c2[2] + c3[3]);
 }
 
+// the 4-block instruction the degree-32 kernel's Gram contraction uses (256 FMAs each)
+__global__ __launch_bounds__(kBlock) void fp64_mfma4_probe_kernel(double* out, int iters) {
+  const int tid = blockIdx.x * kBlock + threadIdx.x;
+  double c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, c6 = 0, c7 = 0;
+  const double a = 1.0 + (tid & 63) * 1e-3, b = 1.0 - (tid & 63) * 1e-3;
+  for (int i = 0; i < iters; ++i) {
+    c0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c2, 0, 0, 0);
+    c3 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c3, 0, 0, 0);
+    c4 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c4, 0, 0, 0);
+    c5 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c5, 0, 0, 0);
+    c6 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c6, 0, 0, 0);
+    c7 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c7, 0, 0, 0);
+  }
+  out[tid] = ((c0 + c1) + (c2 + c3)) + ((c4 + c5) + (c6 + c7));
+}
+
 // Do the f64 MFMA and the FP64 vector FMA overlap on one SIMD?  Even workgroups run the MFMA
 // loop, odd ones the FMA loop with 8x the iterations (same pipe time each); every SIMD hosts
 // both kinds.  Overlapping pipes finish in ~max of the two single-kind runs, a shared pipe
@@ -312,7 +330,9 @@ hipError_t stream_probe(const double* src, double* dst, int64_t n, hipStream_t s
 }
 
 hipError_t fp64_probe(double* out, int blocks, int iters, int use_mfma, hipStream_t s) {
-  if (use_mfma == 2)
+  if (use_mfma == 3)
+    hipLaunchKernelGGL(fp64_mfma4_probe_kernel, dim3(blocks), dim3(kBlock), 0, s, out, iters);
+  else if (use_mfma == 2)
     hipLaunchKernelGGL(fp64_mixed_probe_kernel, dim3(blocks), dim3(kBlock), 0, s, out, iters);
   else if (use_mfma >= 100)
     hipLaunchKernelGGL(fp64_fma_masked_probe_kernel, dim3(blocks), dim3(kBlock), 0, s, out, iters,

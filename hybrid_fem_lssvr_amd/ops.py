@@ -483,7 +483,8 @@ def eval_error(x, W, xq, *, exact=(1.0, math.pi), out=None, stream=None):
 
 
 def fp64_probe(blocks=4096, iters=4096, use_mfma=False, *, device="cuda:0", reps=5):
-    """Measured FP64 FMA (or f64 MFMA) rate in TFLOP/s -- the roofline's compute peak."""
+    """Measured FP64 FMA (use_mfma False), v_mfma_f64_16x16x4 (True / 1) or v_mfma_f64_4x4x4_4b (3)
+    rate in TFLOP/s -- what the roofline's 78.6 TFLOP/s peak sustains in a pure loop."""
     lib = _capi.load()
     out = torch.empty(blocks * 256, dtype=torch.float64, device=device)
     st = _stream(None)
@@ -498,7 +499,9 @@ def fp64_probe(blocks=4096, iters=4096, use_mfma=False, *, device="cuda:0", reps
         e1.record()
         e1.synchronize()
         best = min(best, e0.elapsed_time(e1) * 1e-3)
-    if use_mfma:
+    if int(use_mfma) == 3:
+        flops = 8.0 * 512.0 * iters * blocks * 4      # 8 MFMAs/iter/wave, 4 blocks x 4x4x4 x 2 flop
+    elif use_mfma:
         flops = 4.0 * 2048.0 * iters * blocks * 4     # 4 MFMAs/iter/wave, 16x16x4x2 flop, 4 waves/block
     else:
         flops = 2.0 * 8.0 * iters * blocks * 256

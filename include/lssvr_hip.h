@@ -299,7 +299,10 @@ int lssvr_eval_error(const double* x, const double* W, int64_t ne, int M,
  * lssvr_fp64_probe -- FP64 FMA throughput microbenchmark used to quote the
  * roofline peak: runs `iters` dependent-free fused multiply-adds per lane on
  * `blocks` x 256 threads; out[blocks*256] receives a checksum.  flops = 2 * 8 *
- * iters * blocks * 256 (8 independent accumulators per lane).
+ * iters * blocks * 256 (8 independent accumulators per lane).  use_mfma: 0 = v_fma_f64,
+ * 1 = v_mfma_f64_16x16x4_f64, 3 = v_mfma_f64_4x4x4_4b_f64 (8 per iteration), 2 = MFMA and FMA
+ * workgroups interleaved (do the two pipes overlap? they do not), >= 100 = FMA with
+ * (use_mfma - 100) active lanes per wave.
  */
 int lssvr_fp64_probe(double* out, int blocks, int iters, int use_mfma, void* stream);
 
