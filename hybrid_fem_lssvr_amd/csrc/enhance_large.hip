@@ -255,7 +255,7 @@ __global__ __launch_bounds__(kLargeWaves * 64, 3) void enhance_large_kernel(Enha
       double ak = 0.0, bk = 0.0;
       if constexpr (VC) {
         ak = valid ? p.a_values[e * n + k] : 0.0;
-        bk = valid ? p.da_values[e * n + k] / dm.scl : 0.0;
+        bk = valid ? p.da_values[e * n + k] * (0.5 * dm.oldlen) : 0.0;      // a'/scl, no division
         phi = -fma(bk, d1, fk * inv_scl2) * seed;
       }
       // Recurrence state across the two column halves: p = L''_{j+2} / c_j, r = L'_{j+2}.

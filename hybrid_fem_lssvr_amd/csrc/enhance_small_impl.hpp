@@ -181,7 +181,8 @@ __device__ __forceinline__ void enhance_small_body(const EnhanceArgs& p, const u
         else legendre_d2_scaled<MR>(tk, rho);
         if constexpr (VC) {
           const double ak = stg[kStageArr + lane * (kStageK + 1) + (k & (kStageK - 1))];
-          const double bk = stg[2 * kStageArr + lane * (kStageK + 1) + (k & (kStageK - 1))] / dm.scl;
+          // a'/scl as a'*(h/2): within an ulp of the division, 11 FP64 instructions fewer per point
+          const double bk = stg[2 * kStageArr + lane * (kStageK + 1) + (k & (kStageK - 1))] * (0.5 * dm.oldlen);
           double r1[MR + 1];
           legendre_d1<MR + 1>(tk, r1);        // r1[m] = L'_{m+1}; need L'_{j+2} = r1[j+1]
 #pragma unroll
