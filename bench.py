@@ -418,9 +418,9 @@ def main():
     # if built"): one shared operator applied per element.  Never part of `value`; its own
     # roofline is HBM (88 B per element against ~8 TB/s).
     shared = None
-    if rank == 0 and M <= 16 and args.domain == "wide":
+    if rank == 0 and M <= 33:
         try:
-            op = ops.build_shared_operator(1.0 / 12.0, M, GAMMA, n, device=dev)
+            op = ops.build_shared_operator((hi - lo) / ne_glob, M, GAMMA, n, device=dev)
             Ws = torch.empty((ne_loc, M), dtype=torch.float64, device=dev)
             ts = sorted(ops.enhance_shared(x, u, op, M, n, elem_offset=s0, ne_global=ne_glob,
                                            global_domain=gd, out=Ws, status=status, profiled=True)

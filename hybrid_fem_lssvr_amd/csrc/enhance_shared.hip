@@ -200,6 +200,9 @@ hipError_t enhance_shared(const EnhanceArgs& a, const double* op, hipStream_t s,
     return launch_shared<MM>(a, op, s, o);
     LSSVR_SH(2) LSSVR_SH(3) LSSVR_SH(4) LSSVR_SH(5) LSSVR_SH(6) LSSVR_SH(7) LSSVR_SH(8) LSSVR_SH(9)
     LSSVR_SH(10) LSSVR_SH(11) LSSVR_SH(12) LSSVR_SH(13) LSSVR_SH(14) LSSVR_SH(15) LSSVR_SH(16)
+    LSSVR_SH(17) LSSVR_SH(18) LSSVR_SH(19) LSSVR_SH(20) LSSVR_SH(21) LSSVR_SH(22) LSSVR_SH(23) LSSVR_SH(24)
+    LSSVR_SH(25) LSSVR_SH(26) LSSVR_SH(27) LSSVR_SH(28) LSSVR_SH(29) LSSVR_SH(30) LSSVR_SH(31) LSSVR_SH(32)
+    LSSVR_SH(33)
 #undef LSSVR_SH
     default:
       return hipErrorInvalidValue;

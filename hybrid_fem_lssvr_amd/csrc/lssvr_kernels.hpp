@@ -56,7 +56,7 @@ inline hipError_t launch(K kernel, dim3 grid, dim3 block, hipStream_t s, const L
 hipError_t enhance_small(const EnhanceArgs& a, hipStream_t s, const LaunchOpts* o = nullptr);
 hipError_t enhance_large(const EnhanceArgs& a, hipStream_t s, const LaunchOpts* o = nullptr);
 hipError_t enhance_dual(const EnhanceArgs& a, hipStream_t s, const LaunchOpts* o = nullptr);
-constexpr int kSharedMaxM = 16;  // shared-operator path (uniform meshes): coefficients in VGPRs
+constexpr int kSharedMaxM = 33;  // shared-operator path (uniform meshes): coefficients in VGPRs
 hipError_t enhance_shared(const EnhanceArgs& a, const double* op, hipStream_t s,
                           const LaunchOpts* o = nullptr);
 

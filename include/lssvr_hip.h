@@ -184,7 +184,7 @@ int lssvr_enhance_subset(const double* x, const double* u, int64_t ne_mesh,
  * (hybrid_fem_lssvr_amd.ops.build_shared_operator does exactly that; gamma enters only there).
  * Per element the abscissae, f, scl and the boundary rule of lssvr_enhance stay exact; shared
  * is the operator: relative L2 distance from lssvr_enhance ~ (|x|/h) * 2e-16 (1e-11 at 1e5
- * elements of h = 1/12).  M <= 16;
+ * elements of h = 1/12).  M <= 33;
  * LSSVR_RHS_SIN needs |omega x| < 3e9 (beyond: status = LSSVR_ST_FALLBACK).
  * kernel_ms_host != NULL: blocking, returns the dispatch's own duration (measurement aid).
  * The caller is responsible for the mesh being uniform.

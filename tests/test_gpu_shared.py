@@ -12,7 +12,9 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("cfg", [(24, 9, 16, 1e4, -1.0, 1.0), (8, 5, 5, 1e4, -1.0, 1.0),
                                  (24, 8, 12, 1e4, -1.0, 1.0), (4, 12, 12, 1e6, -1.0, 1.0),
-                                 (4096, 9, 16, 1e4, -1.0, 1.0), (3000, 16, 24, 1e3, -125.0, 125.0)])
+                                 (4096, 9, 16, 1e4, -1.0, 1.0), (3000, 16, 24, 1e3, -125.0, 125.0),
+                                 (24, 33, 64, 1e4, -1.0, 1.0), (2000, 33, 64, 1e4, -1.0, 1.0),
+                                 (1500, 24, 48, 1e5, -60.0, 65.0)])
 def test_shared_matches_general_and_oracle(dev, cfg):
     import hybrid_fem_lssvr_amd as pkg
     from hybrid_fem_lssvr_amd import ops
