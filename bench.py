@@ -89,10 +89,19 @@ def cpu_baseline(nodes_host, values_host, gd, per_core=8):
     done = sum(r[0] for r in res)
     conv = sum(r[1] for r in res)
     busy = sum(r[2] for r in res)
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {
         "value": done / wall,
         "unit": "elements/s",
         "cores": cores,
+        "cpu_model": model,
         "kind": "port",
         "sample": f"{done} elements evenly spaced through the same {ne}-element mesh, "
                   f"per-element scipy SLSQP loop (oracle/lssvr_oracle.py::slsqp_element = "
