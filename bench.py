@@ -71,7 +71,7 @@ def _cpu_worker(args):
     return len(elems), ok, time.perf_counter() - t0
 
 
-def cpu_baseline(nodes_host, values_host, gd, per_core=8):
+def cpu_baseline(nodes_host, values_host, gd, per_core=16):
     """Times the SLSQP loop on a bounded sample of the same mesh with every host core the
     box gives us (one process per core, like N copies of the single-threaded reference)."""
     import multiprocessing as mp
