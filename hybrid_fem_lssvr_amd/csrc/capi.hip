@@ -57,6 +57,25 @@ int fill_enhance_args(lssvr::EnhanceArgs& a, const double* x, const double* u, i
   return LSSVR_OK;
 }
 
+// right-hand side of an enhancement call: named (in-kernel) or tabulated
+int set_rhs(lssvr::EnhanceArgs& a, int rhs_id, const double* rhs_params_host,
+            const double* rhs_values, bool need_values, const char* count_name) {
+  a.rhs_id = rhs_id;
+  if (rhs_id == LSSVR_RHS_SIN) {
+    if (!rhs_params_host) return fail(LSSVR_ERR_RHS, "LSSVR_RHS_SIN needs rhs_params = {amp, omega}");
+    a.rhs_amp = rhs_params_host[0];
+    a.rhs_omega = rhs_params_host[1];
+    return LSSVR_OK;
+  }
+  if (rhs_id == LSSVR_RHS_ARRAY) {
+    if (need_values && !rhs_values)
+      return fail(LSSVR_ERR_RHS, "LSSVR_RHS_ARRAY needs rhs_values[%s*n_colloc]", count_name);
+    a.rhs_values = rhs_values;
+    return LSSVR_OK;
+  }
+  return fail(LSSVR_ERR_RHS, "unknown rhs_id %d", rhs_id);
+}
+
 }  // namespace
 
 namespace {
@@ -92,17 +111,8 @@ int lssvr_enhance(const double* x, const double* u, int64_t ne, int64_t elem_off
   int rc = fill_enhance_args(a, x, u, ne, elem_offset, ne_global, gxmin, gxmax, bc_left, bc_right,
                              M, n_colloc, gamma, W);
   if (rc != LSSVR_OK) return rc;
-  a.rhs_id = rhs_id;
-  if (rhs_id == LSSVR_RHS_SIN) {
-    if (!rhs_params_host) return fail(LSSVR_ERR_RHS, "LSSVR_RHS_SIN needs rhs_params = {amp, omega}");
-    a.rhs_amp = rhs_params_host[0];
-    a.rhs_omega = rhs_params_host[1];
-  } else if (rhs_id == LSSVR_RHS_ARRAY) {
-    if (ne > 0 && !rhs_values) return fail(LSSVR_ERR_RHS, "LSSVR_RHS_ARRAY needs rhs_values[ne*n_colloc]");
-    a.rhs_values = rhs_values;
-  } else {
-    return fail(LSSVR_ERR_RHS, "unknown rhs_id %d", rhs_id);
-  }
+  rc = set_rhs(a, rhs_id, rhs_params_host, rhs_values, ne > 0, "ne");
+  if (rc != LSSVR_OK) return rc;
   a.status = status;
   a.fail_count = fail_count;
   if (solver_id != LSSVR_SOLVER_PRIMAL && solver_id != LSSVR_SOLVER_DUAL &&
@@ -123,17 +133,8 @@ int lssvr_enhance_profiled(const double* x, const double* u, int64_t ne, int64_t
                              M, n_colloc, gamma, W);
   if (rc != LSSVR_OK) return rc;
   if (ne == 0) return fail(LSSVR_ERR_SIZE, "nothing to profile: ne = 0");
-  a.rhs_id = rhs_id;
-  if (rhs_id == LSSVR_RHS_SIN) {
-    if (!rhs_params_host) return fail(LSSVR_ERR_RHS, "LSSVR_RHS_SIN needs rhs_params = {amp, omega}");
-    a.rhs_amp = rhs_params_host[0];
-    a.rhs_omega = rhs_params_host[1];
-  } else if (rhs_id == LSSVR_RHS_ARRAY) {
-    if (!rhs_values) return fail(LSSVR_ERR_RHS, "LSSVR_RHS_ARRAY needs rhs_values[ne*n_colloc]");
-    a.rhs_values = rhs_values;
-  } else {
-    return fail(LSSVR_ERR_RHS, "unknown rhs_id %d", rhs_id);
-  }
+  rc = set_rhs(a, rhs_id, rhs_params_host, rhs_values, true, "ne");
+  if (rc != LSSVR_OK) return rc;
   a.status = status;
   if (solver_id != LSSVR_SOLVER_PRIMAL && solver_id != LSSVR_SOLVER_DUAL &&
       solver_id != LSSVR_SOLVER_PRIMAL_WAVE)
@@ -240,17 +241,8 @@ int lssvr_enhance_subset(const double* x, const double* u, int64_t ne_mesh,
   a.elem_ids = elem_ids;
   a.gamma_values = gamma_values;
   a.ldw = ldw;
-  a.rhs_id = rhs_id;
-  if (rhs_id == LSSVR_RHS_SIN) {
-    if (!rhs_params_host) return fail(LSSVR_ERR_RHS, "LSSVR_RHS_SIN needs rhs_params = {amp, omega}");
-    a.rhs_amp = rhs_params_host[0];
-    a.rhs_omega = rhs_params_host[1];
-  } else if (rhs_id == LSSVR_RHS_ARRAY) {
-    if (nsub > 0 && !rhs_values) return fail(LSSVR_ERR_RHS, "LSSVR_RHS_ARRAY needs rhs_values[nsub*n_colloc]");
-    a.rhs_values = rhs_values;
-  } else {
-    return fail(LSSVR_ERR_RHS, "unknown rhs_id %d", rhs_id);
-  }
+  rc = set_rhs(a, rhs_id, rhs_params_host, rhs_values, nsub > 0, "nsub");
+  if (rc != LSSVR_OK) return rc;
   a.status = status;
   a.fail_count = fail_count;
   if (nsub == 0) return LSSVR_OK;
@@ -272,17 +264,8 @@ int lssvr_enhance_shared(const double* x, const double* u, int64_t ne, int64_t e
   if (M > lssvr::kSharedMaxM)
     return fail(LSSVR_ERR_DEGREE, "shared-operator path: M = %d > %d", M, lssvr::kSharedMaxM);
   if (ne > 0 && !op) return fail(LSSVR_ERR_NULL, "op[(n_colloc+2)*M] must be non-NULL");
-  a.rhs_id = rhs_id;
-  if (rhs_id == LSSVR_RHS_SIN) {
-    if (!rhs_params_host) return fail(LSSVR_ERR_RHS, "LSSVR_RHS_SIN needs rhs_params = {amp, omega}");
-    a.rhs_amp = rhs_params_host[0];
-    a.rhs_omega = rhs_params_host[1];
-  } else if (rhs_id == LSSVR_RHS_ARRAY) {
-    if (ne > 0 && !rhs_values) return fail(LSSVR_ERR_RHS, "LSSVR_RHS_ARRAY needs rhs_values[ne*n_colloc]");
-    a.rhs_values = rhs_values;
-  } else {
-    return fail(LSSVR_ERR_RHS, "unknown rhs_id %d", rhs_id);
-  }
+  rc = set_rhs(a, rhs_id, rhs_params_host, rhs_values, ne > 0, "ne");
+  if (rc != LSSVR_OK) return rc;
   a.status = status;
   a.fail_count = fail_count;
   if (ne == 0) return LSSVR_OK;
