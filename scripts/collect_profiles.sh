@@ -18,7 +18,9 @@ run sq_s1m  --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCL
 run sq_w9   --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/sq_w9 -- python3 scripts/prof_enhance.py 1000000,9,16 3 2 narrow
 run sq_l    --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/sq_l -- python3 scripts/prof_enhance.py 100000,33,64 3 0 narrow
 run sq_l2   --pmc SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/sq_l2 -- python3 scripts/prof_enhance.py 100000,33,64 3 0 narrow
-python3 scripts/pmc_summary.py $O/fetch $O/write $O/fetchL $O/writeL $O/sq_s $O/sq_s2 $O/sq_s1m $O/sq_w9 $O/sq_l $O/sq_l2 > $O/pmc_summary.txt 2>&1
+run fetchS  --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetchS -- python3 scripts/prof_shared.py 10000000,9,16 5 narrow
+run writeS  --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/writeS -- python3 scripts/prof_shared.py 10000000,9,16 5 narrow
+python3 scripts/pmc_summary.py $O/fetch $O/write $O/fetchL $O/writeL $O/fetchS $O/writeS $O/sq_s $O/sq_s2 $O/sq_s1m $O/sq_w9 $O/sq_l $O/sq_l2 > $O/pmc_summary.txt 2>&1
 cp $O/stats/*/*kernel_stats.csv $O/bench_kernel_stats.csv 2>/dev/null
 tail -n 60 $O/pmc_summary.txt
 # bench lines of the same build without the profiler attached

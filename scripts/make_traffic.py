@@ -41,7 +41,9 @@ small = kernel_bytes(prof + "/fetch", prof + "/write", "enhance_small_kernel")
 cal = {"fetch": small["fetch"][1], "write": small["write"][1]}
 res["_calibration_bytes_per_counted_byte"] = cal
 large = kernel_bytes(prof + "/fetchL", prof + "/writeL", "enhance_large_kernel", probe=cal)
-for key, kb, alg in (("M9_n16_ne100008", small, 88 * 100008), ("M33_n64_ne100000", large, 280 * 100000)):
+shared = kernel_bytes(prof + "/fetchS", prof + "/writeS", "enhance_shared_kernel", probe=cal)
+for key, kb, alg in (("M9_n16_ne100008", small, 88 * 100008), ("M33_n64_ne100000", large, 280 * 100000),
+                     ("shared_M9_n16_ne10000000", shared, 88 * 10000000)):
     f, w = kb["fetch"][0], kb["write"][0]
     if f is None or w is None or cal["fetch"] is None:
         continue
