@@ -10,8 +10,11 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# LSSVR_HIP_LIB selects another build of the same ABI (kernel A/B experiments)
-LIB_PATH = os.environ.get("LSSVR_HIP_LIB") or os.path.join(_HERE, "csrc", "liblssvr_hip.so")
+IN_TREE_LIB = os.path.join(_HERE, "csrc", "liblssvr_hip.so")
+# LSSVR_HIP_LIB selects another build of the same ABI -- for kernel A/B experiments in
+# scripts/ only: __graft_entry__.build() and tests/conftest.py refuse to run with it set, so the
+# test suite and the benchmark always exercise the one in-tree library.
+LIB_PATH = os.environ.get("LSSVR_HIP_LIB") or IN_TREE_LIB
 
 ABI_VERSION = 2
 

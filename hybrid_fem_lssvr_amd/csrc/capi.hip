@@ -42,6 +42,7 @@ int fill_enhance_args(lssvr::EnhanceArgs& a, const double* x, const double* u, i
   a.x = x;
   a.u = u;
   a.ne = ne;
+  a.ne_mesh = ne;
   a.elem_offset = elem_offset;
   a.ne_global = ne_global;
   a.gxmin = gxmin;
@@ -49,6 +50,7 @@ int fill_enhance_args(lssvr::EnhanceArgs& a, const double* x, const double* u, i
   a.bc_left = bc_left;
   a.bc_right = bc_right;
   a.gamma = gamma;
+  a.inv_gamma = 1.0 / gamma;
   a.M = M;
   a.n = n_colloc;
   a.W = W;
@@ -166,6 +168,10 @@ int lssvr_step(const double* x, const double* u, int64_t ne, int64_t elem_offset
   if (!diag || !off || !load) return fail(LSSVR_ERR_NULL, "diag, off, load must be non-NULL");
   if (!rhs_params_host) return fail(LSSVR_ERR_RHS, "rhs_params = {amp, omega} required");
   if (nquad < 1 || nquad > 5) return fail(LSSVR_ERR_QUAD, "nquad = %d outside [1,5]", nquad);
+  if (n_colloc < M - 2)
+    return fail(LSSVR_ERR_SOLVER, "lssvr_step: n_colloc = %d < M-2 = %d: the primal normal equations are "
+                                  "rank deficient; use lssvr_p1_assemble + lssvr_enhance (dual solver)",
+                n_colloc, M - 2);
   a.rhs_id = LSSVR_RHS_SIN;
   a.rhs_amp = rhs_params_host[0];
   a.rhs_omega = rhs_params_host[1];
@@ -201,6 +207,9 @@ int lssvr_enhance_varcoef(const double* x, const double* u, int64_t ne, int64_t 
   if (rc != LSSVR_OK) return rc;
   if (ne > 0 && (!a_values || !da_values || !rhs_values))
     return fail(LSSVR_ERR_NULL, "a_values, da_values and rhs_values must be non-NULL");
+  if (n_colloc < M - 2)
+    return fail(LSSVR_ERR_SOLVER, "lssvr_enhance_varcoef: n_colloc = %d < M-2 = %d: the primal normal "
+                                  "equations are rank deficient", n_colloc, M - 2);
   a.rhs_id = LSSVR_RHS_ARRAY;
   a.rhs_values = rhs_values;
   a.a_values = a_values;
@@ -238,7 +247,9 @@ int lssvr_enhance_subset(const double* x, const double* u, int64_t ne_mesh,
     return fail(LSSVR_ERR_SOLVER, "lssvr_enhance_subset: n_colloc < M-2 needs the dual solver, "
                                   "which has no subset form");
   a.gamma = gamma;
+  a.inv_gamma = 1.0 / gamma;
   a.elem_ids = elem_ids;
+  a.ne_mesh = ne_mesh;
   a.gamma_values = gamma_values;
   a.ldw = ldw;
   rc = set_rhs(a, rhs_id, rhs_params_host, rhs_values, nsub > 0, "nsub");

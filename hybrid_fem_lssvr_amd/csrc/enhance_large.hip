@@ -20,8 +20,8 @@
 //      -> lane c owns column c of S (32 rows in registers); the right-hand side rides along as
 //      row/column 31, so forward substitution is free;
 //   4. right-looking LDL^T, both elements in lock step, factor FROZEN IN REGISTERS (lane c
-//      stops at step c); only the pivot rows travel through a two-row LDS ring
-//      (lssvr_wave.hpp::ldlt_solve_frozen);
+//      stops at step c); the pivot row reaches the lanes by DPP row broadcast inside the FMA
+//      (lssvr_wave.hpp::ldlt_solve_dpp), no LDS;
 //   5. backward substitution out of the frozen columns, z_i broadcast through 32 doubles of
 //      LDS; w_{0,1} by a half-wave shuffle reduction.
 // LDS: 5 KB per element (10 KB per wave) -> 3 workgroups of 4 waves per CU; waves are
@@ -131,7 +131,8 @@ __device__ const double kInvScale2[kLP] = {LSSVR_IS8(0), LSSVR_IS8(8), LSSVR_IS8
 
 template <int RHS, bool VC>
 __global__ __launch_bounds__(kLargeWaves * 64, 3) void enhance_large_kernel(EnhanceArgs p,
-                                                                               LargeTables tb) {
+                                                                               LargeTables tb,
+                                                                               unsigned nxcd) {
   __shared__ double2_t lds2[kLargeWaves * kHalf2];      // 2 halves x kHalf2 doubles per wave
   double* const lds = reinterpret_cast<double*>(lds2);
   const int lane = threadIdx.x & 63;
@@ -152,15 +153,26 @@ __global__ __launch_bounds__(kLargeWaves * 64, 3) void enhance_large_kernel(Enha
   // XCD-aware numbering: workgroups go round-robin over the 8 XCDs (each with its own L2), so
   // consecutive element pairs are handed to consecutive workgroups OF ONE XCD -- otherwise every
   // 128-byte line of x / u (8 pairs) is fetched by 8 different L2s (measured: 7.2 MB instead of
-  // 2.5 MB of HBM reads per 1e5 elements).  gridDim.x is a multiple of 8.
-  const int64_t per_xcd = (int64_t)(gridDim.x >> 3) * kLargeWaves;
-  const int64_t pr = (int64_t)(blockIdx.x & 7) * per_xcd + (int64_t)(blockIdx.x >> 3) * kLargeWaves + wave;
+  // 2.5 MB of HBM reads per 1e5 elements).  gridDim.x is a multiple of nxcd (the device's XCD
+  // count, hipDeviceAttributeNumberOfXccs; the mapping is a bijection for any nxcd, so a wrong
+  // guess costs L2 locality, never correctness).
+  const unsigned xcd = blockIdx.x % nxcd, slot = blockIdx.x / nxcd;
+  const int64_t per_xcd = (int64_t)(gridDim.x / nxcd) * kLargeWaves;
+  const int64_t pr = (int64_t)xcd * per_xcd + (int64_t)slot * kLargeWaves + wave;
   if (pr >= npair) return;
   {
     const int64_t e_raw = 2 * pr + h;
-    const bool live = e_raw < p.ne;               // odd ne: half 1 of the last pair idles
+    bool live = e_raw < p.ne;                     // odd ne: half 1 of the last pair idles
     const int64_t e = live ? e_raw : p.ne - 1;    // ... on a duplicate, stores masked
-    const int64_t id = p.elem_ids ? p.elem_ids[e] : e;     // mesh index (lssvr_enhance_subset)
+    int64_t id = e;                               // mesh index (lssvr_enhance_subset)
+    if (p.elem_ids) {
+      id = p.elem_ids[e];
+      if (id < 0 || id >= p.ne_mesh) {     // out-of-range id: nothing of the mesh is touched
+        if (live && c == 0 && p.fail_count) atomicAdd(p.fail_count, 1);
+        live = false;
+        id = 0;
+      }
+    }
     const double a = p.x[id];
     const double b = p.x[id + 1];
     const int64_t eg = id + p.elem_offset;
@@ -399,13 +411,8 @@ __global__ __launch_bounds__(kLargeWaves * 64, 3) void enhance_large_kernel(Enha
     wave_lds_sync();    // G is dead from here on; the pivot-row ring reuses the region
 
     // ---- LDL^T factor + solve of the MR x MR block, rhs carried as row/column 31 ------------
-#ifdef LSSVR_LARGE_LDS_FACTOR
-    bool lane_ok;
-    const double v = ldlt_solve_frozen(col, Bf, Z, c, MR, lane_ok);
-#else
     bool lane_ok;
     const double v = ldlt_solve_dpp(col, Z, c, MR, lane_ok);
-#endif
     const double w0 = d0 - half_sum(((c < MR) ? e0c : 0.0) * v);
     const double w1 = d1 - half_sum(((c < MR) ? e1c : 0.0) * v);
     const double bad = half_sum((lane_ok && fabs(v) < 1.0e300) ? 0.0 : 1.0);
@@ -430,14 +437,15 @@ hipError_t enhance_large(const EnhanceArgs& a, hipStream_t s, const LaunchOpts* 
   static const LargeTables tables = make_large_tables();
   const int64_t npair = (a.ne + 1) / 2;
   int64_t blocks = (npair + kLargeWaves - 1) / kLargeWaves;
-  blocks = (blocks + 7) & ~(int64_t)7;            // XCD-aware numbering needs a multiple of 8
+  const unsigned nxcd = xcd_count();
+  blocks = (blocks + nxcd - 1) / nxcd * nxcd;     // XCD-aware numbering needs a multiple of nxcd
   if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
   const dim3 grid((unsigned)blocks), block(kLargeWaves * 64);
   if (a.a_values)
-    return launch(enhance_large_kernel<LSSVR_RHS_ARRAY, true>, grid, block, s, o, a, tables);
+    return launch(enhance_large_kernel<LSSVR_RHS_ARRAY, true>, grid, block, s, o, a, tables, nxcd);
   if (a.rhs_id == LSSVR_RHS_SIN)
-    return launch(enhance_large_kernel<LSSVR_RHS_SIN, false>, grid, block, s, o, a, tables);
-  return launch(enhance_large_kernel<LSSVR_RHS_ARRAY, false>, grid, block, s, o, a, tables);
+    return launch(enhance_large_kernel<LSSVR_RHS_SIN, false>, grid, block, s, o, a, tables, nxcd);
+  return launch(enhance_large_kernel<LSSVR_RHS_ARRAY, false>, grid, block, s, o, a, tables, nxcd);
 }
 
 }  // namespace lssvr

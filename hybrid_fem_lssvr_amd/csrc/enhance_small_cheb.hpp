@@ -1,0 +1,430 @@
+// Per-element LSSVR enhancement, lane-per-element path, POISSON rows (Dual.py:43-44: -u''):
+// the CHEBYSHEV-MOMENT form of the Legendre Gram contraction.
+//
+// The PDE rows of the reference are pure polynomials of t: rho_j(t) = L''_{j+2}(t), degree j.
+// Writing the bubble part in the Chebyshev basis,  sum_j v_j rho_j = sum_i z_i T_i  (v = Y z,
+// Y the exact triangular connection matrix of cheb_tables.hpp), the Gram matrix of the
+// collocation rows becomes
+//     G_ik = sum_k' T_i(t_k') T_k(t_k') = 1/2 (m_{i+k} + m_{|i-k|}),   m_d = sum_k' T_d(t_k'),
+// i.e. it is determined by 2 MR - 1 power sums instead of MR (MR+1)/2 products: per collocation
+// point the kernel runs the two-term recurrence T_d = 2t T_{d-1} - T_{d-2} up to degree MR-1
+// (one FMA per term; Legendre-type recurrences need two), accumulates m_1..m_{MR-1} (adds), the
+// MR-1 products P_j = sum T_{MR-1} T_j that give the upper moments m_{MR-1+j} = 2 P_j - m_{MR-1-j},
+// and the right-hand side r_i = sum T_i phi -- 3 MR + O(1) instructions per point instead of
+// MR^2/2 + 3 MR.  Same QP, same minimiser (Dual.py:46-78; oracle restatement
+// oracle/lssvr_oracle.py::solve_bc_eliminated; numpy prototype of exactly this arrangement
+// scripts/proto/cheb_moment.py::solve_cheb_kernel: <= 7e-16 from the 60-digit minimiser over
+// random M, n, gamma, h, x0 -- as accurate as the direct Gram in every regime).
+//
+// Boundary rows (Dual.py:61-76).  t_a = off + scl a and t_b = off + scl b are -1 and +1 up to
+// the rounding of numpy's mapdomain, |1 + t_a|, |1 - t_b| ~ eps |x| / h.  With
+//     e_a = 1 + t_a, e_b = 1 - t_b (exact), sigma = (e_a + e_b)/2, delta = (e_a - e_b)/2,
+//     L_p(-1 + e) = (-1)^p (1 - a_p e + O((a_p e)^2)),  a_p = p (p+1) / 2,
+// the eliminated rows  w_{0,1} = d - C v  are, to first order,
+//     p even: C0 = 1 - a sigma, C1 = a delta;     p odd: C0 = (a-1) delta, C1 = 1 - (a-1) sigma.
+// The neglected terms are (a e)^2 / 4 relative: the fast path is taken while
+// a_max max(|e_a|, |e_b|) < 1e-6 (|x|/h up to ~1e8 at degree 8); beyond, the whole wave takes
+// the exact Legendre recurrence and a dense ridge (cheb_slow_build: out of line, on scratch).
+// The ridge eps (N + C_z^T C_z), N = Y^T Y, C_z = C Y, is built from compile-time tables
+// (alpha, b, N of cheb_tables.hpp) with its first-order terms in sigma / delta.
+// The whole system is carried scaled by 2 (S2 = m_{i+k} + m_{|i-k|} + 2 eps R) so that the 1/2
+// of the product formula costs nothing.
+#pragma once
+#include "cheb_tables.hpp"
+#include "lssvr_device.hpp"
+#include "lssvr_kernels.hpp"
+
+namespace lssvr {
+
+constexpr int kReseed = 64;   // in-kernel rhs: the (sin, cos) rotation is re-seeded every 64 points
+
+template <int M, int RHS>
+constexpr int kChebTilePerWave =
+    (RHS == LSSVR_RHS_ARRAY && 64 * 9 > 64 * M) ? 64 * 9 : 64 * M;   // output tile / rhs staging
+
+
+// ---------------------------------------------------------------------------------------------
+// Cold path (a wave with any element beyond the first-order range, |x|/h >~ 1e8): exact boundary
+// rows by the Legendre recurrence, C_z = C Y, dense ridge.  Out of line, on a per-lane scratch
+// buffer, with run-time loops: inlined, its arrays cost the hot path 62 VGPRs and a resident wave
+// per SIMD; like this it costs nothing but the call.
+// ---------------------------------------------------------------------------------------------
+template <int M>
+struct ChebSlow {
+  static constexpr int MR = M - 2;
+  static constexpr int NT = MR * (MR + 1) / 2;
+  static constexpr int kMom = 0;                    // in : m_0 .. m_{2MR-2}
+  static constexpr int kRhs = kMom + 2 * MR - 1;    // in/out: rhs2[MR]
+  static constexpr int kS = kRhs + MR;              // out: S2, packed lower triangle [NT]
+  static constexpr int kD = kS + NT;                // out: d0, d1
+  static constexpr int kC0 = kD + 2;                // out: C0[MR], C1[MR] (v-basis)
+  static constexpr int kC1 = kC0 + MR;
+  static constexpr int kZ0 = kC1 + MR;              // work: C_z = C Y
+  static constexpr int kZ1 = kZ0 + MR;
+  static constexpr int kSize = kZ1 + MR;
+};
+
+template <int M>
+__device__ __attribute__((noinline)) void cheb_slow_build(double* __restrict__ buf, double ta,
+                                                          double tb, double gl, double gr,
+                                                          double eps2) {
+  using L = ChebSlow<M>;
+  constexpr int MR = L::MR;
+  const double idet = rcp_newton(tb - ta);
+  const double d0 = (tb * gl - ta * gr) * idet;
+  const double d1 = (gr - gl) * idet;
+  buf[L::kD] = d0;
+  buf[L::kD + 1] = d1;
+  // L_p(ta), L_p(tb), p = 2 .. M-1:  (p+1) L_{p+1} = (2p+1) t L_p - p L_{p-1}
+  double am1 = 1.0, a0 = ta, bm1 = 1.0, b0 = tb;
+#pragma nounroll
+  for (int pp = 1; pp < M - 1; ++pp) {
+    const double inv = 1.0 / (double)(pp + 1);
+    const double a1 = ((double)(2 * pp + 1) * ta * a0 - (double)pp * am1) * inv;
+    const double b1 = ((double)(2 * pp + 1) * tb * b0 - (double)pp * bm1) * inv;
+    am1 = a0; a0 = a1;
+    bm1 = b0; b0 = b1;
+    buf[L::kC0 + pp - 1] = (tb * a1 - ta * b1) * idet;      // column j = pp - 1 <-> degree pp + 1
+    buf[L::kC1 + pp - 1] = (b1 - a1) * idet;
+  }
+#pragma nounroll
+  for (int i = 0; i < MR; ++i) {
+    double s0 = 0.0, s1 = 0.0;
+#pragma nounroll
+    for (int j = (i & 1); j <= i; j += 2) {
+      s0 = fma(buf[L::kC0 + j], cheb::kY[j][i], s0);
+      s1 = fma(buf[L::kC1 + j], cheb::kY[j][i], s1);
+    }
+    buf[L::kZ0 + i] = s0;
+    buf[L::kZ1 + i] = s1;
+  }
+#pragma nounroll
+  for (int i = 0; i < MR; ++i) {
+    const double z0 = buf[L::kZ0 + i], z1 = buf[L::kZ1 + i];
+#pragma nounroll
+    for (int k = 0; k <= i; ++k) {
+      double cc = fma(z0, buf[L::kZ0 + k], z1 * buf[L::kZ1 + k]);
+      if (((i + k) & 1) == 0) cc += cheb::kN[i][k];
+      buf[L::kS + tri(i, k)] = fma(eps2, cc, buf[L::kMom + i + k] + buf[L::kMom + i - k]);
+    }
+    buf[L::kRhs + i] = fma(eps2, fma(z0, d0, z1 * d1), buf[L::kRhs + i]);
+  }
+}
+
+template <int M, int RHS>
+__device__ __forceinline__ void enhance_small_body_cheb(const EnhanceArgs& p, const unsigned block,
+                                                        double* __restrict__ tile) {
+  constexpr int MR = M - 2;
+  constexpr int TD = MR > 0 ? MR : 1;
+  constexpr int NT = MR * (MR + 1) / 2;
+  constexpr int kStageK = 8;
+
+  const int tid = threadIdx.x;
+  const int64_t e = (int64_t)block * kBlock + tid;
+  double w[M];
+  int st = LSSVR_ST_OK;
+
+  const bool scattered = p.elem_ids != nullptr || (p.ldw != 0 && p.ldw != M);
+  // Every lane runs the body (lanes past the end of the last wave on a duplicate of the last
+  // element, their stores masked): tabulated inputs are loaded cooperatively by the wave.
+  bool live = e < p.ne;
+  const int64_t ec = live ? e : p.ne - 1;                   // position in this launch
+  const int lane = tid & 63;
+  {
+    int64_t id = ec;                                        // mesh index of this element
+    if (p.elem_ids) {
+      id = p.elem_ids[ec];
+      if (id < 0 || id >= p.ne_mesh) {       // out-of-range id: nothing of the mesh is touched
+        if (live && p.fail_count) atomicAdd(p.fail_count, 1);
+        live = false;
+        id = 0;
+      }
+    }
+    const double a = p.x[id];
+    const double b = p.x[id + 1];
+    const int64_t eg = id + p.elem_offset;
+    // Dual.py:65-75: Dirichlet value only on a global-boundary element whose end
+    // point equals the global end point exactly
+    const double gl = (eg == 0 && a == p.gxmin) ? p.bc_left : p.u[id];
+    const double gr = (eg == p.ne_global - 1 && b == p.gxmax) ? p.bc_right : p.u[id + 1];
+    const double inv_gamma = p.gamma_values ? rcp_newton(p.gamma_values[id]) : p.inv_gamma;
+
+    const DomainMap dm = map_params(a, b);
+    const int n = p.n;
+    const double step = dm.oldlen / (double)(n - 1);
+    // 1 / scl^2 = (h/2)^2: within 2 ulp of 1 / fl(fl(2/h)^2), no division
+    const double hh = 0.5 * dm.oldlen;
+    const double inv_scl2 = hh * hh;
+    const double eps2 = (2.0 * inv_gamma) * (inv_scl2 * inv_scl2);     // 2 / (gamma scl^4)
+
+    // --- boundary rows, first order in (e_a, e_b) -------------------------------------------
+    const double ta = dm.off + dm.scl * a;
+    const double tb = dm.off + dm.scl * b;
+    const double ea = 1.0 + ta, eb = 1.0 - tb;
+    const double sig = 0.5 * (ea + eb), del = 0.5 * (ea - eb);
+    const double idet = 0.5 * fma(sig, 1.0 + sig, 1.0);            // 1 / (tb - ta) = 1 / (2 - 2 sigma)
+    constexpr double kAmax = 0.5 * (double)((M - 1) * M);
+    // (a non-finite map -- degenerate element -- is not "slow": it ends in the status test)
+    const bool slow = kAmax * fmax(fabs(ea), fabs(eb)) >= 1.0e-6;
+    const bool any_slow = __any(slow);
+    double d0 = (tb * gl - ta * gr) * idet;
+    double d1 = (gr - gl) * idet;
+
+    // cold path's per-lane scratch (never touched by a wave that stays on the fast path)
+    [[maybe_unused]] double slowbuf[MR > 0 ? ChebSlow<M>::kSize : 1];
+    if constexpr (MR == 0) {
+      if (any_slow) {
+        const double idx = rcp_newton(tb - ta);
+        d0 = (tb * gl - ta * gr) * idx;
+        d1 = (gr - gl) * idx;
+      }
+    }
+
+    if constexpr (MR == 0) {
+      w[0] = d0;
+      w[1] = d1;
+      if (!(fabs(d0) < 1.0e300 && fabs(d1) < 1.0e300)) st = LSSVR_ST_FALLBACK;
+    } else {
+      // --- moments over the collocation points ----------------------------------------------
+      double mom[TD], P[TD], rv[TD];
+#pragma unroll
+      for (int i = 0; i < MR; ++i) mom[i] = P[i] = rv[i] = 0.0;
+
+      // In-kernel rhs f = amp sin(fl(omega x_k)) without a sin per point: (s~, c~) =
+      // (sin, cos)(th0 + k dth) is carried by a rotation and numpy's argument rounding
+      // arg_k = fl(omega x_k) is restored to first order, sin(arg_k) = s~ + c~ delta_k,
+      // delta_k = (arg_k - th0) - k dth (|delta| ~ |omega x| eps; a wave with any |delta| > 1e-7
+      // takes the per-point sin).  The pair is carried pre-multiplied by kappa = -2 amp / scl^2
+      // (phi2_k = -2 f(x_k) / scl^2 comes out of the correction FMA) and re-seeded every kReseed
+      // points, so the rotation's own rounding never exceeds ~64 eps.
+      double rs = 0.0, rc = 1.0, sd = 0.0, cd = 1.0, th0 = 0.0, dth = 0.0, kappa = 0.0;
+      if constexpr (RHS == LSSVR_RHS_SIN) {
+        dth = p.rhs_omega * step;
+        sincos_tab(dth, sd, cd, p.trig);
+        kappa = -2.0 * (p.rhs_amp * inv_scl2);
+      }
+      [[maybe_unused]] const double fscale = -2.0 * inv_scl2;
+      // Tabulated rhs ([element][point]): the wave loads kStageK points of its 64 rows at a time
+      // with consecutive lanes on consecutive doubles into LDS at pitch kStageK + 1 (conflict-free
+      // when every lane then reads its own row); a lane walking its own row would touch 64 cache
+      // lines per load instruction.
+      [[maybe_unused]] double* const stg = tile + (tid >> 6) * kChebTilePerWave<M, RHS>;
+      [[maybe_unused]] const int64_t e0 = (int64_t)block * kBlock + (tid & ~63);
+      for (int k0 = 0; k0 < n; k0 += kReseed) {
+        if constexpr (RHS == LSSVR_RHS_SIN) {
+          const double x0 = (k0 == 0) ? a : fma((double)k0, step, a);
+          th0 = p.rhs_omega * x0;
+          sincos_tab(th0, rs, rc, p.trig);
+          rs *= kappa;
+          rc *= kappa;
+        }
+        const int k1 = min(k0 + kReseed, n);
+        for (int k = k0; k < k1; ++k) {
+          if constexpr (RHS == LSSVR_RHS_ARRAY) {
+            if ((k & (kStageK - 1)) == 0) {
+              __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+#pragma unroll
+              for (int i = 0; i < kStageK; ++i) {
+                const int idx = i * 64 + lane;
+                const int row = idx / kStageK, kk = idx % kStageK;
+                const int64_t er = e0 + row;
+                const bool in = (er < p.ne) && (k + kk < n);
+                stg[row * (kStageK + 1) + kk] = in ? p.rhs_values[er * n + (k + kk)] : 0.0;
+              }
+              __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+            }
+          }
+          // np.linspace / mapdomain, two roundings each (step == 0 needs h < 1e-320, where
+          // scl = 2/h overflows and the element ends in the linear fallback whatever x_k is)
+          const double xk = (k == n - 1) ? b : (double)k * step + a;
+          const double tk = dm.off + dm.scl * xk;
+          double phi2;
+          if constexpr (RHS == LSSVR_RHS_SIN) {
+            const double arg = p.rhs_omega * xk;
+            const double delta = fma(-(double)(k - k0), dth, arg - th0);
+            phi2 = fma(rc, delta, rs);
+            if (__any(!(fabs(delta) < 1.0e-7))) phi2 = kappa * sin_tab(arg, p.trig);
+            const double rs_next = fma(rs, cd, rc * sd);
+            rc = fma(rc, cd, -(rs * sd));
+            rs = rs_next;
+          } else {
+            phi2 = stg[lane * (kStageK + 1) + (k & (kStageK - 1))] * fscale;
+          }
+          // Chebyshev values T_0 .. T_{MR-1}, moments, upper-moment products, right-hand side
+          double T[TD];
+          T[0] = 1.0;
+          if constexpr (MR > 1) T[1] = tk;
+          const double tt = tk + tk;
+#pragma unroll
+          for (int d = 2; d < MR; ++d) T[d] = fma(tt, T[d - 1], -T[d - 2]);
+          rv[0] += phi2;
+#pragma unroll
+          for (int d = 1; d < MR; ++d) {
+            mom[d] += T[d];
+            P[d] = fma(T[MR - 1], T[d], P[d]);
+            rv[d] = fma(T[d], phi2, rv[d]);
+          }
+        }
+      }
+      mom[0] = (double)n;
+      // all moments m_0 .. m_{2MR-2}:  m_{MR-1+j} = 2 P_j - m_{MR-1-j}
+      double mm[2 * TD - 1];
+#pragma unroll
+      for (int d = 0; d < MR; ++d) mm[d] = mom[d];
+#pragma unroll
+      for (int j = 1; j < MR; ++j) mm[MR - 1 + j] = fma(2.0, P[j], -mom[MR - 1 - j]);
+
+      // --- S2 = m_{i+k} + m_{|i-k|} + 2 eps (N + C_z^T C_z),  rhs2 = r2 + 2 eps C_z^T d ----------
+      double G[NT];
+      if (any_slow) {
+        using L = ChebSlow<M>;
+#pragma unroll
+        for (int d = 0; d < 2 * MR - 1; ++d) slowbuf[L::kMom + d] = mm[d];
+#pragma unroll
+        for (int i = 0; i < MR; ++i) slowbuf[L::kRhs + i] = rv[i];
+        cheb_slow_build<M>(slowbuf, ta, tb, gl, gr, eps2);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) G[t] = slowbuf[L::kS + t];
+#pragma unroll
+        for (int i = 0; i < MR; ++i) rv[i] = slowbuf[L::kRhs + i];
+        d0 = slowbuf[L::kD];
+        d1 = slowbuf[L::kD + 1];
+      } else {
+        const double es = eps2 * sig, ed = eps2 * del;
+        const double e_d0 = eps2 * d0, e_d1 = eps2 * d1;
+        const double q_ev = eps2 * fma(del, d1, -(sig * d0));
+        const double q_od = eps2 * fma(del, d0, -(sig * d1));
+#pragma unroll
+        for (int i = 0; i < MR; ++i) {
+#pragma unroll
+          for (int k = 0; k <= i; ++k) {
+            const double Q = cheb::kAlpha[i] * cheb::kB[k] + cheb::kB[i] * cheb::kAlpha[k];
+            double v = mm[i + k] + mm[i - k];
+            if (((i + k) & 1) == 0) {
+              const double R0 = cheb::kN[i][k] + cheb::kAlpha[i] * cheb::kAlpha[k];
+              v = fma(R0, eps2, v);
+              v = fma(-Q, es, v);
+            } else {
+              v = fma(Q, ed, v);
+            }
+            G[tri(i, k)] = v;
+          }
+          if ((i & 1) == 0) rv[i] = fma(cheb::kB[i], q_ev, fma(cheb::kAlpha[i], e_d0, rv[i]));
+          else rv[i] = fma(cheb::kB[i], q_od, fma(cheb::kAlpha[i], e_d1, rv[i]));
+        }
+      }
+
+      // --- LDL^T (lower, in place; unit L below the diagonal, diagonal holds 1/d_j).  No
+      // square roots, no pre-scaling (elimination of an SPD matrix is invariant under symmetric
+      // diagonal scaling up to rounding).  A zero / non-finite pivot turns into inf / NaN in
+      // 1/d_j and reaches every later entry; a negative one is caught by the sign test.
+      bool ok = true;
+#pragma unroll
+      for (int j = 0; j < MR; ++j) {
+        ok = ok && (G[tri(j, j)] > 0.0);
+        const double rinv = rcp_newton(G[tri(j, j)]);
+        G[tri(j, j)] = rinv;
+#pragma unroll
+        for (int c = j + 1; c < MR; ++c) {
+          const double lcj = G[tri(c, j)] * rinv;              // L_cj = a_cj / d_j
+#pragma unroll
+          for (int i = c; i < MR; ++i)
+            G[tri(i, c)] = fma(-G[tri(i, j)], lcj, G[tri(i, c)]);
+          G[tri(c, j)] = lcj;
+        }
+      }
+      // forward  L y = rhs
+#pragma unroll
+      for (int i = 0; i < MR; ++i) {
+        double s = rv[i];
+#pragma unroll
+        for (int j = 0; j < i; ++j) s = fma(-G[tri(i, j)], rv[j], s);
+        rv[i] = s;
+      }
+      // backward L^T z = D^-1 y
+#pragma unroll
+      for (int i = MR - 1; i >= 0; --i) {
+        double s = rv[i] * G[tri(i, i)];
+#pragma unroll
+        for (int j = i + 1; j < MR; ++j) s = fma(-G[tri(j, i)], rv[j], s);
+        rv[i] = s;
+      }
+      // v = Y z (Legendre bubble coefficients), w_{0,1} = d - C v
+      double C0[TD], C1[TD];
+      if (any_slow) {
+#pragma unroll
+        for (int j = 0; j < MR; ++j) {
+          C0[j] = slowbuf[ChebSlow<M>::kC0 + j];
+          C1[j] = slowbuf[ChebSlow<M>::kC1 + j];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < MR; ++j) {
+          const double aj = cheb::kSlope[j];
+          if ((j & 1) == 0) {
+            C0[j] = fma(-aj, sig, 1.0);
+            C1[j] = aj * del;
+          } else {
+            C0[j] = (aj - 1.0) * del;
+            C1[j] = fma(-(aj - 1.0), sig, 1.0);
+          }
+        }
+      }
+      double w0 = d0, w1 = d1;
+#pragma unroll
+      for (int j = 0; j < MR; ++j) {
+        double v = 0.0;
+#pragma unroll
+        for (int i = j; i < MR; i += 2) v = fma(cheb::kY[j][i], rv[i], v);
+        w[j + 2] = v;
+        w0 = fma(-C0[j], v, w0);
+        w1 = fma(-C1[j], v, w1);
+        ok = ok && (fabs(v) < 1.0e300);
+      }
+      w[0] = w0;
+      w[1] = w1;
+      ok = ok && (fabs(w0) < 1.0e300) && (fabs(w1) < 1.0e300);
+      if (!ok) st = LSSVR_ST_FALLBACK;
+    }
+
+    if (st != LSSVR_ST_OK) {
+      // Dual.py:164-169: linear interpolant of (g_l, g_r) as a Legendre series
+#pragma unroll
+      for (int i = 0; i < M; ++i) w[i] = 0.0;
+      w[0] = 0.5 * (gl + gr);
+      w[1] = 0.5 * (gr - gl);
+      if (live && p.fail_count) atomicAdd(p.fail_count, 1);
+    }
+    if (live && p.status) p.status[id] = st;
+    if (live && scattered) {
+      // heterogeneous launch: rows go to the mesh index, ldw apart (direct stores)
+      double* const Wrow = p.W + id * (p.ldw ? p.ldw : (int64_t)M);
+#pragma unroll
+      for (int i = 0; i < M; ++i) Wrow[i] = w[i];
+    }
+  }
+  if (scattered) return;
+
+  // --- coalesced store: each wave transposes its own 64 x M tile through LDS --------
+  // (wave-private, so no workgroup barrier: a wave that finishes early stores early;
+  // LDS operations of one wave execute in order)
+  double* const wt = tile + (tid >> 6) * kChebTilePerWave<M, RHS>;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // (the staging reads are done)
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int i = 0; i < M; ++i) wt[lane * M + i] = w[i];
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int64_t base = ((int64_t)block * kBlock + (tid & ~63)) * M;
+  const int64_t total = p.ne * M;
+#pragma unroll
+  for (int i = 0; i < M; ++i) {
+    const int64_t idx = base + (int64_t)i * 64 + lane;
+    // write-once output: non-temporal stores leave less for the end-of-kernel L2 write-back
+    if (idx < total) __builtin_nontemporal_store(wt[i * 64 + lane], &p.W[idx]);
+  }
+}
+
+}  // namespace lssvr

@@ -23,6 +23,7 @@
 // is lane-local (no cross-lane traffic, no LDS in the loop, no divergence), and
 // all 64 lanes do useful FP64 work.  Measured numbers: DESIGN.md.
 #pragma once
+#include "enhance_small_cheb.hpp"
 #include "lssvr_device.hpp"
 #include "lssvr_kernels.hpp"
 #include "lssvr_p1.hpp"
@@ -53,11 +54,19 @@ __device__ __forceinline__ void enhance_small_body(const EnhanceArgs& p, const u
   const bool scattered = p.elem_ids != nullptr || (p.ldw != 0 && p.ldw != M);
   // Every lane runs the body (lanes past the end of the last wave on a duplicate of the last
   // element, their stores masked): the tabulated inputs are loaded cooperatively by the wave.
-  const bool live = e < p.ne;
+  bool live = e < p.ne;
   const int64_t ec = live ? e : p.ne - 1;                   // position in this launch
   const int lane = tid & 63;
   {
-    const int64_t id = p.elem_ids ? p.elem_ids[ec] : ec;    // mesh index of this element
+    int64_t id = ec;                                        // mesh index of this element
+    if (p.elem_ids) {
+      id = p.elem_ids[ec];
+      if (id < 0 || id >= p.ne_mesh) {       // out-of-range id: nothing of the mesh is touched
+        if (live && p.fail_count) atomicAdd(p.fail_count, 1);
+        live = false;
+        id = 0;
+      }
+    }
     const double a = p.x[id];
     const double b = p.x[id + 1];
     const int64_t eg = id + p.elem_offset;
@@ -309,8 +318,14 @@ __device__ __forceinline__ void enhance_small_body(const EnhanceArgs& p, const u
 // waves); 4: <= 128 VGPRs for launches that can fill a fourth wave slot.
 template <int M, int RHS, bool VC, int MINW>
 __global__ __launch_bounds__(kBlock, MINW) void enhance_small_kernel(EnhanceArgs p) {
-  __shared__ double tile[(kBlock / 64) * kSmallTilePerWave<M, RHS, VC>];
-  enhance_small_body<M, RHS, VC>(p, blockIdx.x, tile);
+  if constexpr (VC) {
+    __shared__ double tile[(kBlock / 64) * kSmallTilePerWave<M, RHS, VC>];
+    enhance_small_body<M, RHS, VC>(p, blockIdx.x, tile);
+  } else {
+    // Poisson rows: the Chebyshev-moment form (enhance_small_cheb.hpp)
+    __shared__ double tile[(kBlock / 64) * kChebTilePerWave<M, RHS>];
+    enhance_small_body_cheb<M, RHS>(p, blockIdx.x, tile);
+  }
 }
 
 // One launch for a whole step of the hot path on one mesh: blocks [0, eblocks) run the
@@ -322,7 +337,7 @@ __global__ __launch_bounds__(kBlock) void step_small_kernel(EnhanceArgs p, P1Arg
                                                              unsigned eblocks) {
   __shared__ double tile[kBlock * M];
   if (blockIdx.x < eblocks) {
-    enhance_small_body<M, LSSVR_RHS_SIN, false>(p, blockIdx.x, tile);
+    enhance_small_body_cheb<M, LSSVR_RHS_SIN>(p, blockIdx.x, tile);
   } else {
     const int64_t i = (int64_t)(blockIdx.x - eblocks) * kBlock + threadIdx.x;
     if (i <= a.ne) p1_node<true>(a, q, i);

@@ -16,6 +16,7 @@ struct EnhanceArgs {
   const double* u;
   int64_t ne, elem_offset, ne_global;
   double gxmin, gxmax, bc_left, bc_right, gamma;
+  double inv_gamma;         // 1 / gamma, rounded on the host (the scalar-gamma path divides nowhere)
   int M, n;
   int rhs_id;
   double rhs_amp, rhs_omega;
@@ -27,7 +28,10 @@ struct EnhanceArgs {
   // rows are addressed by the MESH index, the tabulated arrays (rhs_values, a_values,
   // da_values) by k; gamma_values[mesh index] replaces gamma when non-NULL; W rows are ldw
   // doubles apart (0 = M)
+  // An id outside [0, ne_mesh) touches NOTHING (no load, no store; status has no slot for
+  // it): the element is skipped and counted in fail_count.
   const int64_t* elem_ids;
+  int64_t ne_mesh;          // elements of the mesh the ids index (== ne when elem_ids is NULL)
   const double* gamma_values;
   int64_t ldw;
   double* W;
@@ -51,6 +55,22 @@ inline hipError_t launch(K kernel, dim3 grid, dim3 block, hipStream_t s, const L
   else
     hipLaunchKernelGGL(kernel, grid, block, 0, s, args...);
   return hipGetLastError();
+}
+
+// XCDs (L2 domains) of the current device, hipDeviceAttributeNumberOfXccs (8 on MI355X); cached
+// per device, 1 when the runtime cannot say.  Used only for L2-affine workgroup numbering.
+inline unsigned xcd_count() {
+  static thread_local int cached_dev = -1;
+  static thread_local unsigned cached = 1;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 1;
+  if (dev != cached_dev) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeNumberOfXccs, dev) != hipSuccess || v < 1) v = 1;
+    cached = (unsigned)v;
+    cached_dev = dev;
+  }
+  return cached;
 }
 
 hipError_t enhance_small(const EnhanceArgs& a, hipStream_t s, const LaunchOpts* o = nullptr);

@@ -158,80 +158,6 @@ __device__ __forceinline__ double ldlt_solve(double (&col)[kLP], double* __restr
 
 
 // ---------------------------------------------------------------------------
-// LDS-lean variant used by enhance_large.hip: the factor stays FROZEN IN REGISTERS.
-// Lane c stops updating its column at step c (the update of step j runs under the lane
-// mask c > j), so after the elimination col[i], i > c, is the final a_ic = d_c L_ic,
-// col[c] the pivot d_c and col[kRhsRow] the forward-substituted right-hand side.  Only the
-// pivot rows travel through LDS, in a ring of two rows (R: 2 x kSL doubles): row j is read
-// during step j while row j+1 is written.  The backward substitution then reads its factor
-// entries from registers; z_i is broadcast through Z (32 doubles).
-// LDS per system: 2*34 + 32 doubles instead of the 32 x 34 stored factor -- this is what
-// lets three waves per SIMD fit in 160 KB.
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ double ldlt_solve_frozen(double (&col)[kLP], double* __restrict__ R,
-                                                    double* __restrict__ Z, int c, int nsys,
-                                                    bool& pivots_ok) {
-  int cc = c;
-  asm volatile("" : "+v"(cc));     // opaque copies: keep the 31 lane masks / uniform
-  int ns = nsys;                   // conditions from being hoisted out of the element loop
-  asm volatile("" : "+s"(ns));
-  // pivot checks: d_j <= -0 sets the sign bit of the OR of the high words; a zero or non-finite
-  // pivot makes 1/d_j inf / NaN and reaches the solution, where the caller tests finiteness
-  int signs = 0;
-  R[c] = col[0];
-  wave_lds_sync();
-#pragma unroll
-  for (int j = 0; j < kLP - 1; ++j) {
-    if (j < ns) {
-      const double* const Rj = R + (j & 1) * kSL;
-      double* const Rn = R + ((j + 1) & 1) * kSL;
-      const double dj = Rj[j];
-      signs |= __double2hiint(dj);
-      const double rinv = rcp_newton(dj);
-      if (cc > j) {
-        const double tcj = col[j] * rinv;                       // a_jc / d_j
-        // row j+1 of every live column first, then publish it (one step of software
-        // pipelining: its LDS round trip overlaps the remaining updates of step j).
-        // Only live lanes publish: the last thing lane c ever writes is therefore its own
-        // pivot d_c = a_cc (row c, step c-1), which stays at slot (c & 1), position c.
-        col[j + 1] = fma(-Rj[j + 1], tcj, col[j + 1]);
-        if (j + 1 < kLP - 1) Rn[c] = col[j + 1];
-        if ((j + 2) & 1) col[j + 2] = fma(-Rj[j + 2], tcj, col[j + 2]);
-#pragma unroll
-        for (int i = (j + 3) & ~1; i < kLP; i += 2) {
-          const double2_t l2 = *reinterpret_cast<const double2_t*>(&Rj[i]);
-          col[i] = fma(-l2[0], tcj, col[i]);
-          col[i + 1] = fma(-l2[1], tcj, col[i + 1]);
-        }
-      }
-      wave_lds_sync();
-    }
-  }
-  pivots_ok = signs >= 0;
-  // backward substitution L^T z = D^-1 y out of the frozen columns:
-  //   z_t = (a_{rhs,t} - sum_{i>t} a_it z_i) / d_t
-  double Y = col[kRhsRow];
-  double rinv = rcp_newton(R[(c & 1) * kSL + c]);
-  if (c >= nsys) {
-    Y = 0.0;
-    rinv = 0.0;
-  }
-  wave_lds_sync();
-  asm volatile("" : "+s"(ns));
-#pragma unroll
-  for (int i = kLP - 2; i >= 1; --i) {
-    if (i < ns) {
-      Z[c] = Y * rinv;
-      wave_lds_sync();
-      const double zi = Z[i];
-      if (cc < i) Y = fma(-col[i], zi, Y);
-    }
-  }
-  return (c < nsys) ? Y * rinv : 0.0;
-}
-
-
-// ---------------------------------------------------------------------------
 // The same elimination with NO LDS AT ALL in the factorisation: the pivot row is broadcast
 // by DPP.  gfx90a+ allows DPP on the 64-bit VOP2 v_fmac_f64 for row_newbcast (lane n of each
 // 16-lane row feeds the whole row), so  a_ic -= a_ji t_c  is ONE instruction
@@ -242,8 +168,11 @@ __device__ __forceinline__ double ldlt_solve_frozen(double (&col)[kLP], double* 
 // pivot reciprocal is taken element-wise on the copy whose lane (j & 15) holds d_j and
 // reaches every lane through the same broadcast.  Everything runs with the full EXEC mask
 // (a DPP source lane must be active); a column freezes because its multiplier is zeroed
-// from its own pivot step on.  Versus the LDS version (ldlt_solve_frozen): 250 ds_read_b128
-// + 62 ds_read/ds_write_b64 fewer per element pair, 7 more VALU instructions per step.
+// from its own pivot step on (lane c stops updating its column at step c, so after the
+// elimination col[i], i > c, is the final a_ic = d_c L_ic, col[c] the pivot and col[kRhsRow] the
+// forward-substituted right-hand side).  Versus publishing the pivot rows through an LDS ring
+// (round 1, removed): 250 ds_read_b128 + 62 ds_read/ds_write_b64 fewer per element pair, 7 more
+// VALU instructions per step, 5-7 % faster.
 // ---------------------------------------------------------------------------
 template <int I>
 __device__ __forceinline__ void fmac_rowbcast(double& acc, double rowdata, double mul) {

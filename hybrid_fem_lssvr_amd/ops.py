@@ -37,6 +37,36 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+def _check_buffers(ne, M, n_colloc, x, *, out=None, status=None, fail_count=None, rhs_values=None,
+                   n_rhs_rows=None):
+    """Caller-supplied buffers become raw device pointers: a wrong-sized tensor would be an
+    out-of-bounds device access, so sizes are checked here.  Returns (out, status), allocated
+    when not given."""
+    if out is None:
+        out = torch.empty((ne, M), dtype=torch.float64, device=x.device)
+    else:
+        _dev(out, "out")
+        if out.numel() != ne * M:
+            raise ValueError(f"out must hold ne*M = {ne * M} doubles, got {out.numel()}")
+    if status is None:
+        status = torch.empty((ne,), dtype=torch.int32, device=x.device)
+    else:
+        _dev(status, "status", torch.int32)
+        if status.numel() != ne:
+            raise ValueError(f"status must hold ne = {ne} int32, got {status.numel()}")
+    if fail_count is not None:
+        _dev(fail_count, "fail_count", torch.int32)
+        if fail_count.numel() < 1:
+            raise ValueError("fail_count must hold one int32")
+    if rhs_values is not None:
+        _dev(rhs_values, "rhs_values")
+        rows = ne if n_rhs_rows is None else n_rhs_rows
+        if rhs_values.numel() != rows * n_colloc:
+            raise ValueError(f"rhs_values must hold {rows}*n_colloc = {rows * n_colloc} doubles, "
+                             f"got {rhs_values.numel()}")
+    return out, status
+
+
 def _stream(stream):
     if stream is None:
         return torch.cuda.current_stream().cuda_stream
@@ -70,22 +100,9 @@ def enhance(x, u, M, gamma, n_colloc=12, *, rhs=(POISSON_AMP, POISSON_OMEGA), rh
         else:
             ends = torch.stack([x[0], x[-1]]).cpu()
             global_domain = (float(ends[0]), float(ends[1]))
-    if out is None:
-        out = torch.empty((ne, M), dtype=torch.float64, device=x.device)
-    else:
-        _dev(out, "out")
-        if out.numel() != ne * M:
-            raise ValueError("out must hold ne*M doubles")
-    if status is None:
-        status = torch.empty((ne,), dtype=torch.int32, device=x.device)
-    else:
-        _dev(status, "status", torch.int32)
-    if fail_count is not None:
-        _dev(fail_count, "fail_count", torch.int32)
+    out, status = _check_buffers(ne, M, n_colloc, x, out=out, status=status, fail_count=fail_count,
+                                 rhs_values=rhs_values)
     if rhs_values is not None:
-        _dev(rhs_values, "rhs_values")
-        if rhs_values.numel() != ne * n_colloc:
-            raise ValueError("rhs_values must hold ne*n_colloc doubles")
         rhs_id, params = RHS_ARRAY, None
     else:
         rhs_id, params = RHS_SIN, _capi.rhs_params(*rhs)
@@ -184,20 +201,15 @@ def enhance_shared(x, u, op, M, n_colloc, *, rhs=(POISSON_AMP, POISSON_OMEGA), r
     _dev(u, "u")
     _dev(op, "op")
     ne = x.numel() - 1
-    if op.numel() != (n_colloc + 2) * M or not op.is_contiguous():
+    if x.numel() != u.numel() or x.dim() != 1:
+        raise ValueError("x and u must be 1-D with equal length ne+1")
+    if op.dim() != 2 or op.shape[0] != n_colloc + 2 or op.shape[1] != M or not op.is_contiguous():
         raise ValueError("op must be a contiguous float64[(n_colloc+2), M] tensor")
     if ne_global is None:
         ne_global = elem_offset + ne
-    if out is None:
-        out = torch.empty((ne, M), dtype=torch.float64, device=x.device)
-    else:
-        _dev(out, "out")
-    if status is None:
-        status = torch.empty((ne,), dtype=torch.int32, device=x.device)
-    else:
-        _dev(status, "status", torch.int32)
+    out, status = _check_buffers(ne, M, n_colloc, x, out=out, status=status, fail_count=fail_count,
+                                 rhs_values=rhs_values)
     if rhs_values is not None:
-        _dev(rhs_values, "rhs_values")
         rhs_id, params = RHS_ARRAY, None
     else:
         rhs_id, params = RHS_SIN, _capi.rhs_params(*rhs)
@@ -224,10 +236,11 @@ def enhance_profiled(x, u, M, gamma, n_colloc=12, *, rhs=(POISSON_AMP, POISSON_O
     _dev(x, "x")
     _dev(u, "u")
     ne = x.numel() - 1
+    if x.numel() != u.numel() or x.dim() != 1:
+        raise ValueError("x and u must be 1-D with equal length ne+1")
     if ne_global is None:
         ne_global = elem_offset + ne
-    if out is None:
-        out = torch.empty((ne, M), dtype=torch.float64, device=x.device)
+    out, status = _check_buffers(ne, M, n_colloc, x, out=out, status=status)
     ms = ctypes.c_float(0.0)
     rc = lib.lssvr_enhance_profiled(_ptr(x), _ptr(u), ne, int(elem_offset), int(ne_global),
                                     float(global_domain[0]), float(global_domain[1]),
@@ -258,8 +271,14 @@ class StepPlan:
             "off": torch.empty(ne, dtype=torch.float64, device=dev),
             "load": torch.empty(ne + 1, dtype=torch.float64, device=dev),
         }
-        self.W = out if out is not None else torch.empty((ne, M), dtype=torch.float64, device=dev)
-        self.status = status if status is not None else torch.empty(ne, dtype=torch.int32, device=dev)
+        if x.numel() != u.numel() or x.dim() != 1:
+            raise ValueError("x and u must be 1-D with equal length ne+1")
+        for k, cnt in (("diag", ne + 1), ("off", ne), ("load", ne + 1)):
+            _dev(self.bands[k], k)
+            if self.bands[k].numel() != cnt:
+                raise ValueError(f"bands[{k!r}] must hold {cnt} doubles")
+        self.W, self.status = _check_buffers(ne, M, n_colloc, x, out=out, status=status,
+                                             fail_count=fail_count)
         self.fail_count = fail_count
         self._keep = (x, u, _capi.rhs_params(*rhs))
         self._args = (_ptr(x), _ptr(u), ne, int(elem_offset), int(ne_global),
@@ -292,10 +311,9 @@ def enhance_varcoef(x, u, M, gamma, n_colloc, a_values, da_values, rhs_values, *
     if global_domain is None:
         ends = torch.stack([x[0], x[-1]]).cpu()
         global_domain = (float(ends[0]), float(ends[1]))
-    if out is None:
-        out = torch.empty((ne, M), dtype=torch.float64, device=x.device)
-    if status is None:
-        status = torch.empty((ne,), dtype=torch.int32, device=x.device)
+    if x.numel() != u.numel() or x.dim() != 1:
+        raise ValueError("x and u must be 1-D with equal length ne+1")
+    out, status = _check_buffers(ne, M, n_colloc, x, out=out, status=status, fail_count=fail_count)
     rc = lib.lssvr_enhance_varcoef(_ptr(x), _ptr(u), ne, int(elem_offset), int(ne_global),
                                    float(global_domain[0]), float(global_domain[1]),
                                    float(bc[0]), float(bc[1]), int(M), int(n_colloc), float(gamma),

@@ -13,6 +13,9 @@ GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    if os.environ.get("LSSVR_HIP_LIB"):
+        raise pytest.UsageError("LSSVR_HIP_LIB is set: the test suite only runs against the in-tree "
+                                "hybrid_fem_lssvr_amd/csrc/liblssvr_hip.so")
 
 
 def load_golden(name):

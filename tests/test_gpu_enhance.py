@@ -287,3 +287,74 @@ def test_enhance_sharded_single_rank_chunks(dev):
                                  gather=False)
     torch.cuda.synchronize()
     assert Wg is None and torch.equal(Wl, Wref)
+
+
+def test_step_and_varcoef_refuse_rank_deficient_primal(dev):
+    """n_colloc < M-2: the BC-eliminated primal Gram is rank deficient and float64 returns O(1)
+    errors with status OK (oracle: 2.06 relative at M=17, n=12).  lssvr_enhance reroutes to the
+    dual solver; lssvr_step and lssvr_enhance_varcoef have no such route and must refuse."""
+    import torch
+    from hybrid_fem_lssvr_amd import ops, _capi
+    nodes = np.linspace(-1, 1, 25)
+    x, u = _t(nodes, dev), _t(np.sin(np.pi * nodes), dev)
+    plan = ops.StepPlan(x, u, 17, 1e4, 12, global_domain=(-1.0, 1.0))
+    with pytest.raises(_capi.LssvrHipError, match="rank deficient"):
+        plan.launch()
+    z = torch.ones((24, 12), dtype=torch.float64, device=dev)
+    with pytest.raises(_capi.LssvrHipError, match="rank deficient"):
+        ops.enhance_varcoef(x, u, 17, 1e4, 12, z, z.clone(), z.clone(), global_domain=(-1.0, 1.0))
+    # the boundary of the regime (n == M-2) is accepted by both
+    ops.StepPlan(x, u, 14, 1e4, 12, global_domain=(-1.0, 1.0)).launch()
+    ops.enhance_varcoef(x, u, 14, 1e4, 12, z, z.clone(), z.clone(), global_domain=(-1.0, 1.0))
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("n", [257, 1024, 4096])
+def test_in_kernel_sin_many_points(dev, n):
+    """The in-kernel right-hand side carries (sin, cos) by a rotation that is re-seeded every 64
+    points: RHS_SIN must agree with the tabulated numpy values at the 1e-13 bar up to the ABI's
+    largest collocation count (an unseeded rotation drifts to 1.5e-13 in sin at n = 4096)."""
+    import torch
+    from hybrid_fem_lssvr_amd import ops
+    ne, M = 300, 9
+    nodes = np.linspace(-3, 5, ne + 1) * 1.0
+    nodes[1:-1] += 1e-3 * np.sin(np.arange(1, ne))           # non-uniform h up to ~2 x the mean
+    values = np.sin(np.pi * nodes)
+    x = _t(nodes, dev)
+    f = _t(orc.poisson_rhs(ops.colloc_points(x, n).cpu().numpy()), dev)
+    W1, s1 = ops.enhance(x, _t(values, dev), M, 1e4, n, rhs_values=f)
+    W2, s2 = ops.enhance(x, _t(values, dev), M, 1e4, n)
+    torch.cuda.synchronize()
+    assert int(s1.sum()) == 0 and int(s2.sum()) == 0
+    assert orc.rel_l2_coef(W1.cpu().numpy(), W2.cpu().numpy()).max() <= 1e-13
+
+
+def test_wrapper_buffer_validation(dev):
+    """Caller buffers travel as raw pointers: every wrapper rejects wrong sizes in Python."""
+    import torch
+    from hybrid_fem_lssvr_amd import ops
+    nodes = np.linspace(-1, 1, 25)
+    x, u = _t(nodes, dev), _t(np.sin(np.pi * nodes), dev)
+    gd = (-1.0, 1.0)
+    small = torch.empty((23, 9), dtype=torch.float64, device=dev)
+    st_small = torch.empty(23, dtype=torch.int32, device=dev)
+    op = ops.build_shared_operator(2.0 / 24, 9, 1e4, 16, device=dev)
+    for call in (
+        lambda: ops.enhance(x, u, 9, 1e4, 16, global_domain=gd, out=small),
+        lambda: ops.enhance(x, u, 9, 1e4, 16, global_domain=gd, status=st_small),
+        lambda: ops.enhance(x, u, 9, 1e4, 16, global_domain=gd, rhs_values=torch.zeros(24 * 15, dtype=torch.float64, device=dev)),
+        lambda: ops.enhance_shared(x, u, op, 9, 16, global_domain=gd, out=small),
+        lambda: ops.enhance_shared(x, u, op, 9, 16, global_domain=gd, status=st_small),
+        lambda: ops.enhance_shared(x, u, op, 9, 16, global_domain=gd, rhs_values=torch.zeros(7, dtype=torch.float64, device=dev)),
+        lambda: ops.enhance_shared(x, u, op[:, :8].contiguous(), 9, 16, global_domain=gd),
+        lambda: ops.enhance_profiled(x, u, 9, 1e4, 16, global_domain=gd, out=small),
+        lambda: ops.enhance_profiled(x, u, 9, 1e4, 16, global_domain=gd, status=st_small),
+        lambda: ops.StepPlan(x, u, 9, 1e4, 16, global_domain=gd, out=small),
+        lambda: ops.StepPlan(x, u, 9, 1e4, 16, global_domain=gd, status=st_small),
+        lambda: ops.enhance_varcoef(x, u, 9, 1e4, 16, *(torch.ones((24, 16), dtype=torch.float64, device=dev),) * 3,
+                                    global_domain=gd, out=small),
+        lambda: ops.enhance_varcoef(x, u, 9, 1e4, 16, *(torch.ones((24, 16), dtype=torch.float64, device=dev),) * 3,
+                                    global_domain=gd, status=st_small),
+    ):
+        with pytest.raises(ValueError):
+            call()

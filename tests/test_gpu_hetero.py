@@ -98,3 +98,32 @@ def test_subset_argument_errors(dev):
     W = torch.zeros((20, 12), dtype=torch.float64, device=dev)
     with pytest.raises(_capi.LssvrHipError):
         ops.enhance_subset(x, u, 12, 1e4, 5, W, global_domain=(nodes[0], nodes[-1]))    # n < M-2
+
+
+def test_subset_out_of_range_ids_touch_nothing(dev):
+    """An id outside [0, ne_mesh) must not become an out-of-bounds access: the element is
+    skipped (no load, no store) and counted in fail_count; valid ids of the same launch are
+    enhanced as usual (both kernels: lane mapping M = 9, wave mapping M = 33)."""
+    import torch
+    from hybrid_fem_lssvr_amd import ops
+    _, nodes, values = _mesh(90, 15)
+    x = torch.as_tensor(nodes, device=dev)
+    u = torch.as_tensor(values, device=dev)
+    gd = (nodes[0], nodes[-1])
+    for M, n in [(9, 16), (33, 64)]:
+        # guard rows around W and status catch a stray write next to the arrays
+        Wbig = torch.full((92, M), 7.0, dtype=torch.float64, device=dev)
+        stbig = torch.full((92,), -5, dtype=torch.int32, device=dev)
+        W, st = Wbig[1:91], stbig[1:91]
+        fc = torch.zeros(1, dtype=torch.int32, device=dev)
+        ids = torch.as_tensor(np.array([5, -1, 90, 17, 1 << 40, -(1 << 50), 89], dtype=np.int64), device=dev)
+        ops.enhance_subset(x, u, M, 1e4, n, W, elem_ids=ids, global_domain=gd, status=st, fail_count=fc)
+        torch.cuda.synchronize()
+        assert int(fc.item()) == 4
+        Wh, sth = Wbig.cpu().numpy(), stbig.cpu().numpy()
+        good = np.zeros(92, dtype=bool)
+        good[[6, 18, 90]] = True
+        assert np.all(Wh[~good] == 7.0) and np.all(sth[~good] == -5)
+        assert np.all(sth[good] == 0)
+        Wfull, _ = ops.enhance(x, u, M, 1e4, n, global_domain=gd)
+        assert np.array_equal(Wh[good], Wfull.cpu().numpy()[[5, 17, 89]])
