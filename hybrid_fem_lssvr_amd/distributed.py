@@ -55,7 +55,44 @@ class ShardPlan:
         return rem + (e - cut) // max(base, 1)
 
 
-def allgather_rows(local, plan, rank, group=None, chunks=1, out=None, compute_chunk=None):
+ALLGATHER_ALGOS = ("collective", "pairs")
+
+
+def allgather_flat(out, src, rank, world, *, algo="collective", group=None):
+    """Every rank contributes ``src`` (1-D, equal length on all ranks) and receives all of them,
+    rank-major, in ``out`` (1-D, ``world * src.numel()``).
+
+    ``collective``: the backend's all-gather (RCCL ``ncclAllGather`` on MI355X; on a fully
+    connected xGMI node RCCL picks its own ring / direct algorithm).
+    ``pairs``: direct all-pairs exchange -- one batched group of point-to-point sends and
+    receives, a different peer on every one of the 7 xGMI links at once, each block landing in
+    its final place (a ring is bound by one link, the direct exchange drives
+    all of them).  Both forms are asynchronous on the current stream for device tensors.
+    """
+    n = src.numel()
+    if out.numel() != world * n:
+        raise ValueError(f"out must hold world*n = {world * n} elements, got {out.numel()}")
+    if world == 1:
+        out.copy_(src)
+        return out
+    if algo == "collective":
+        dist.all_gather_into_tensor(out, src, group=group)
+        return out
+    if algo != "pairs":
+        raise ValueError(f"unknown all-gather algorithm {algo!r} (choose from {ALLGATHER_ALGOS})")
+    ops_ = []
+    for off in range(1, world):
+        to, frm = (rank + off) % world, (rank - off) % world
+        ops_.append(dist.P2POp(dist.isend, src, to, group=group))
+        ops_.append(dist.P2POp(dist.irecv, out[frm * n:(frm + 1) * n], frm, group=group))
+    out[rank * n:(rank + 1) * n].copy_(src)
+    for req in dist.batch_isend_irecv(ops_):
+        req.wait()
+    return out
+
+
+def allgather_rows(local, plan, rank, group=None, chunks=1, out=None, compute_chunk=None,
+                   algo="collective"):
     """Stitch per-rank row blocks into the global array, on every rank.
 
     local: [max_size or size(rank), C] tensor (rows beyond ``plan.size(rank)`` ignored)
@@ -63,6 +100,7 @@ def allgather_rows(local, plan, rank, group=None, chunks=1, out=None, compute_ch
     compute_chunk(r0, r1, dst): optional; fills ``dst`` (a [r1-r0, C] view of the local
            block) for local rows [r0, r1) on the current stream.  With ``chunks > 1`` the
            gather of chunk i overlaps the computation of chunk i+1 (CUDA tensors only).
+    algo:  "collective" or "pairs" (:func:`allgather_flat`).
     Returns ``out`` [plan.ne, C].
     """
     world = plan.world
@@ -106,27 +144,27 @@ def allgather_rows(local, plan, rank, group=None, chunks=1, out=None, compute_ch
             ready.record(main)
             comm.wait_event(ready)
             with torch.cuda.stream(comm):
-                _gather_chunk(dst, src, world, group)
+                _gather_chunk(dst, src, rank, world, group, algo)
                 _scatter_rows(out, dst, plan, r0, r1)
                 stage.record_stream(comm)
                 out.record_stream(comm)
         else:
-            _gather_chunk(dst, src, world, group)
+            _gather_chunk(dst, src, rank, world, group, algo)
             _scatter_rows(out, dst, plan, r0, r1)
     if use_streams:
         main.wait_stream(comm)
     return out
 
 
-def _gather_chunk(dst, src, world, group):
+def _gather_chunk(dst, src, rank, world, group, algo="collective"):
     if world == 1:
         dst[0].copy_(src)
         return
     if dst.is_contiguous():
-        dist.all_gather_into_tensor(dst.view(-1), src.contiguous().view(-1), group=group)
+        allgather_flat(dst.view(-1), src.contiguous().view(-1), rank, world, algo=algo, group=group)
     else:
         tmp = torch.empty((world,) + tuple(src.shape), dtype=src.dtype, device=src.device)
-        dist.all_gather_into_tensor(tmp.view(-1), src.contiguous().view(-1), group=group)
+        allgather_flat(tmp.view(-1), src.contiguous().view(-1), rank, world, algo=algo, group=group)
         dst.copy_(tmp)
 
 
@@ -140,7 +178,8 @@ def _scatter_rows(out, staged, plan, r0, r1):
 
 
 def enhance_sharded(x_local, u_local, plan, rank, M, gamma, n_colloc=12, *, global_domain,
-                    rhs=None, bc=(0.0, 0.0), group=None, chunks=4, gather=True, out=None):
+                    rhs=None, bc=(0.0, 0.0), group=None, chunks=4, gather=True, out=None,
+                    algo="collective"):
     """Rank-local enhancement of this rank's shard + (optionally) the stitched global W.
 
     x_local/u_local: float64 device tensors of the shard's nodes (``plan.node_slice(rank)``).
@@ -172,7 +211,7 @@ def enhance_sharded(x_local, u_local, plan, rank, M, gamma, n_colloc=12, *, glob
     if pad > n_loc:
         W_buf[n_loc:].zero_()      # the collective never ships uninitialised memory
     Wg = allgather_rows(W_buf, plan, rank, group=group, chunks=chunks, out=out,
-                        compute_chunk=compute)
+                        compute_chunk=compute, algo=algo)
     return W_buf[:n_loc], status, Wg
 
 

@@ -22,7 +22,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, ne, M, n, chunks, q):
+def _worker(rank, world, port, ne, M, n, chunks, q, algo="collective"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -44,19 +44,20 @@ def _worker(rank, world, port, ne, M, n, chunks, q):
             dst.copy_(torch.from_numpy(W))
 
         local = torch.zeros((plan.max_size, M), dtype=torch.float64)
-        Wg = allgather_rows(local, plan, rank, chunks=chunks, compute_chunk=compute)
+        Wg = allgather_rows(local, plan, rank, chunks=chunks, compute_chunk=compute, algo=algo)
         q.put((rank, Wg.numpy()))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("ne,chunks", [(11, 1), (12, 3), (7, 4)])
-def test_two_rank_gloo_stitch(ne, chunks):
+@pytest.mark.parametrize("ne,chunks,algo", [(11, 1, "collective"), (12, 3, "collective"), (7, 4, "collective"),
+                                            (11, 2, "pairs"), (7, 4, "pairs")])
+def test_two_rank_gloo_stitch(ne, chunks, algo):
     M, n, world = 6, 8, 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, ne, M, n, chunks, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ne, M, n, chunks, q, algo)) for r in range(world)]
     for p in procs:
         p.start()
     got = dict(q.get(timeout=120) for _ in range(world))
@@ -78,3 +79,54 @@ def test_single_rank_allgather_is_identity():
     local = torch.arange(27, dtype=torch.float64).reshape(9, 3)
     out = allgather_rows(local, plan, 0, chunks=2)
     assert torch.equal(out, local)
+
+
+def _flat_worker(rank, world, port, n, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from hybrid_fem_lssvr_amd.distributed import ALLGATHER_ALGOS, allgather_flat
+        src = torch.arange(n, dtype=torch.float64) + 1000.0 * rank
+        res = {}
+        for algo in ALLGATHER_ALGOS:
+            out = torch.full((world * n,), -1.0, dtype=torch.float64)
+            allgather_flat(out, src, rank, world, algo=algo)
+            res[algo] = out.numpy().copy()
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_allgather_flat_algorithms_agree(world):
+    """The direct all-pairs exchange (one peer per xGMI link on MI355X) and the backend's
+    all-gather deliver the same rank-major array on every rank."""
+    n = 37
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_flat_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    want = np.concatenate([np.arange(n) + 1000.0 * r for r in range(world)])
+    for r in range(world):
+        for algo, arr in got[r].items():
+            assert np.array_equal(arr, want), (r, algo)
+
+
+def test_bench_refuses_wrong_rank_count():
+    """bench.py --gpus N must never run another rank count: WORLD_SIZE != N exits non-zero before
+    anything touches a GPU (and WORLD_SIZE unset makes it spawn its own N ranks -- covered by the
+    one-GPU gloo rehearsal in tests/test_gpu_sharded.py)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8"], env=env,
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "refusing" in r.stderr and r.stdout == ""

@@ -55,10 +55,16 @@ def test_tridiag_dirichlet_solve(dev, ne):
         r = diag[1:-1] * u[1:-1] + off[:-1] * u[:-2] + off[1:] * u[2:] - load[1:-1]
         assert np.max(np.abs(r)) <= 1e-13 * np.max(np.abs(diag)) * scale * max(1.0, np.log2(ne))
     # Forward agreement: the P1 Laplacian has cond ~ ne^2, so two backward-stable float64
-    # solvers (LAPACK banded LU here; recursive substructuring on the device) may differ by
-    # up to ~cond*eps.  Measured: LAPACK itself is 3e-13 (ne=1025) / 9e-11 (ne=1e5) from a
-    # long-double Thomas; the device solver stays within a few times that.
-    assert np.max(np.abs(u - ref)) <= 1e-15 * scale * max(ne, 10) ** 1.5
+    # solvers (LAPACK banded LU here; recursive substructuring on the device) differ by up to
+    # ~cond*eps; LAPACK itself is 3e-13 (ne=1025) / 9e-11 (ne=1e5) from a long-double Thomas.
+    # Pinned at ~5x what the device solver measured on an MI355X (scripts/measure_bars.py, round 2):
+    # max|u - ref| = 1.6e-15 (24), 4.4e-13 (511), 6.6e-14 (512), 3.9e-13 (513), 3.0e-13 (514),
+    # 6.5e-13 (1025), 3.8e-10 (16385), 1.4e-8 (1e5), 3.5e-7 (1234567).
+    assert np.max(np.abs(u - ref)) <= TRIDIAG_FORWARD_BAR[ne] * scale
+
+
+TRIDIAG_FORWARD_BAR = {1: 0.0, 2: 1e-15, 3: 1e-15, 24: 1e-14, 511: 2.5e-12, 512: 2.5e-12, 513: 2.5e-12,
+                       514: 2.5e-12, 1025: 4e-12, 16385: 2e-9, 100000: 7e-8, 1234567: 2e-6}
 
 
 @pytest.mark.parametrize("ne", [1, 2, 3, 24, 2047, 2048, 2049, 100000, 1234567, 10000000])
@@ -180,7 +186,9 @@ def test_varcoef_config5(dev):
         ex = np.sin(np.pi * xq)
         # manufactured solution: same L2 error as the CPU restatement, and below plain P1
         assert abs(np.linalg.norm(uq - ex) - np.linalg.norm(uo - ex)) <= 1e-10 * np.linalg.norm(ex)
-        assert np.linalg.norm(uq - ex) < np.linalg.norm(p1 - ex)
+        # measured (scripts/measure_bars.py): the enhancement's error is 1/1.90 .. 1/1.91 of P1's
+        # at all three sizes (the nodal error of the P1 solve dominates both)
+        assert np.linalg.norm(uq - ex) < np.linalg.norm(p1 - ex) / 1.7
 
 
 def test_facade_reference_demo(dev, golden):

@@ -95,3 +95,55 @@ def test_sharded_pipeline_over_rccl_single_rank(dev):
     assert p.exitcode == 0 and nbad == 0
     assert np.max(np.abs(u - ref.fem_values)) <= 1e-14
     assert np.max(np.abs(Wg - ref.enhanced.W.cpu().numpy())) <= 1e-13
+
+
+def _run_bench(extra_args, env_extra, timeout=600):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + extra_args, env=env,
+                       capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]          # exactly ONE JSON line on stdout
+    return json.loads(lines[0])
+
+
+def test_bench_self_launches_its_ranks(dev):
+    """`python bench.py --gpus 2` with no launcher must start two ranks itself (rehearsed over
+    gloo on the one GPU of this box: RCCL refuses two ranks on one device), run BASELINE config
+    3's strong-scaling mode (here on a smaller total) and report the stitched rate with both
+    all-gather algorithms."""
+    out = _run_bench(["--gpus", "2", "--steps", "4", "--warmup", "1", "--elements", "200008"],
+                     {"LSSVR_BENCH_BACKEND": "gloo"})
+    assert out["n_gpus"] == 2 and out["ranks_in_process_group"] == 2
+    assert out["scaling"] == "strong" and out["config"]["elements_total"] == 200008
+    assert out["config"]["elements_per_gpu"] == 100004 and out["config"]["fallback_elements"] == 0
+    assert out["value"] > 0 and out["value_with_allgather"] > 0
+    for key, nbytes in (("stitch_u", 16), ("stitch_W", 72)):
+        st = out[key]
+        assert st["picked"] in ("collective", "pairs")
+        for algo in ("collective", "pairs"):
+            a = st["algorithms"][algo]
+            assert "error" not in a, a
+            assert a["own_block_intact"] and a["bytes_per_element"] == nbytes
+            assert a["bytes_received_per_rank_per_step"] == 100004 * nbytes
+    assert out["weak_scaling"]["value"] > 0 and out["one_rank_same_workload"]["value"] > 0
+
+
+def test_bench_single_rank_line(dev):
+    """The N = 1 line the driver records: metric / config of BASELINE config 2, roofline and
+    cpu_baseline objects, event-timed value consistent with the host clock."""
+    out = _run_bench(["--steps", "50", "--warmup", "5"], {})
+    assert out["n_gpus"] == 1 and out["config"]["elements_total"] == 100008
+    assert out["dtype"] == "f64" and out["unit"] == "elements/s" and out["vs_baseline"] is None
+    rf = out["roofline"]
+    assert rf["bound"] == "fp64-valu" and 0 < rf["frac"] < 1.5 and rf["kernel_us_avg"] > 1
+    assert abs(rf["achieved"] / rf["peak"] - rf["frac"]) < 1e-12
+    assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["value"] > 0
+    assert out["ms_per_step"] <= out["host_wall_ms_per_step"] * 1.05
+    assert out["accuracy"]["rel_l2_vs_float64_kkt_oracle"] < 1e-13
+    assert out["config"]["fallback_elements"] == 0
