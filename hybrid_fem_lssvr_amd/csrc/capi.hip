@@ -86,10 +86,10 @@ int enhance_dispatch(const lssvr::EnhanceArgs& a, int solver_id, hipStream_t s,
                      const lssvr::LaunchOpts* o) {
   // Fewer collocation points than bubble coefficients: the primal normal equations are rank
   // deficient (float64 returns O(1) errors there), the dual Gram system is well conditioned.
-  if (solver_id != LSSVR_SOLVER_DUAL && a.n < a.M - 2 && !a.a_values) solver_id = LSSVR_SOLVER_DUAL;
+  if (solver_id != LSSVR_SOLVER_DUAL && a.n < a.M - 2) solver_id = LSSVR_SOLVER_DUAL;
   if (solver_id == LSSVR_SOLVER_DUAL) {
-    if (a.n > 29) return fail(LSSVR_ERR_SIZE, "dual solver: n_colloc = %d > 29", a.n);
-    if (a.M > 32) return fail(LSSVR_ERR_DEGREE, "dual solver: M = %d > 32", a.M);
+    if (a.n > 64) return fail(LSSVR_ERR_SIZE, "dual solver: n_colloc = %d > 64", a.n);
+    if (a.elem_ids) return fail(LSSVR_ERR_SOLVER, "dual solver: no subset form");
     return check_launch(lssvr::enhance_dual(a, s, o), "enhance_dual");
   }
   if (a.M <= lssvr::kSmallMaxM && solver_id == LSSVR_SOLVER_PRIMAL)
@@ -207,9 +207,6 @@ int lssvr_enhance_varcoef(const double* x, const double* u, int64_t ne, int64_t 
   if (rc != LSSVR_OK) return rc;
   if (ne > 0 && (!a_values || !da_values || !rhs_values))
     return fail(LSSVR_ERR_NULL, "a_values, da_values and rhs_values must be non-NULL");
-  if (n_colloc < M - 2)
-    return fail(LSSVR_ERR_SOLVER, "lssvr_enhance_varcoef: n_colloc = %d < M-2 = %d: the primal normal "
-                                  "equations are rank deficient", n_colloc, M - 2);
   a.rhs_id = LSSVR_RHS_ARRAY;
   a.rhs_values = rhs_values;
   a.a_values = a_values;
@@ -217,9 +214,8 @@ int lssvr_enhance_varcoef(const double* x, const double* u, int64_t ne, int64_t 
   a.status = status;
   a.fail_count = fail_count;
   if (ne == 0) return LSSVR_OK;
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (M <= lssvr::kSmallMaxM) return check_launch(lssvr::enhance_small(a, s), "enhance_small(varcoef)");
-  return check_launch(lssvr::enhance_large(a, s), "enhance_large(varcoef)");
+  // (n_colloc < M-2: rank-deficient primal normal equations -> the dual Gram solver)
+  return enhance_dispatch(a, LSSVR_SOLVER_PRIMAL, reinterpret_cast<hipStream_t>(stream), nullptr);
 }
 
 int lssvr_enhance_subset(const double* x, const double* u, int64_t ne_mesh,

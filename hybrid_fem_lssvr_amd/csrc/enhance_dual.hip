@@ -1,19 +1,37 @@
-// Per-element LSSVR enhancement, DUAL form -- the formulation BASELINE.json's north_star
-// names: the Legendre kernel Gram matrix over the collocation (and boundary) rows and the
-// dense solve (K + I/gamma) alpha = y (dual form):
+// Per-element LSSVR enhancement, DUAL form -- the formulation BASELINE.json's north_star names:
+// the Legendre kernel Gram matrix over the collocation points and the dense solve
+// (K + I/gamma) alpha = y, one independent system per element (dual form;
+// the QP is Dual.py:46-78).
 //
-//   Z = [Ahat; B]  ((n+2) x M),   K = Z Z^T + diag(eps I_n, 0, 0),   K [lam; mu] = [ftil; g],
-//   w = Z^T [lam; mu],            eps = 1 / (gamma scl^4),  Ahat = -L''(t_k), B = L(t_a), L(t_b).
+//   rows      a_k = -L''(t_k)   (Poisson; -a_k L'' - (a'_k/scl) L' for variable coefficients),
+//             B   = [L(t_a); L(t_b)]                     (the two boundary rows, Dual.py:61-76)
+//   system    [[A A^T + eps I, A B^T], [B A^T, B B^T]] [lam; mu] = [f~; g],  w = A^T lam + B^T mu,
+//             eps = 1 / (gamma scl^4).
 //
-// K[i][j] = sum_p Z_ip Z_jp is exactly north_star's K(x_i,x_j) = sum_p phi_p(x_i) phi_p(x_j)
-// with the PDE rows' feature map phi_p = -L_p''.  Same wave mapping as enhance_large.hip
-// (two elements per wave, f64 MFMA for the Gram, LDL^T in registers) with the roles of the
-// two indices swapped: the contraction runs over the M Legendre indices.
+// The 2 x 2 boundary block B B^T is well conditioned and is taken as the FIRST (block) pivot,
+// analytically: with Pi = I - B^T (B B^T)^-1 B the Schur complement is the kernel matrix of the
+// projected feature map,
+//     K = (A Pi)(A Pi)^T,     (K + eps I) lam = f~ - A w_bc,     w = w_bc + (A Pi)^T lam,
+//     w_bc = B^T (B B^T)^-1 g    (the minimum-norm coefficients that satisfy the boundary rows),
+// an n x n SPD system -- K_ij = sum_p phi_p(x_i) phi_p(x_j) is north_star's Gram matrix with the
+// boundary-projected PDE feature map.  cond(K + eps I) ~ |A|^2 gamma scl^4 reaches 1e22 on
+// BASELINE's meshes (plain Cholesky breaks down), so the solve is, per SURVEY.md
+// section 7 "Hard parts":
+//   * symmetric Jacobi equilibration  d_i = (K_ii + eps)^-1/2,
+//   * LU with PARTIAL PIVOTING (row per lane: the pivot search is a wave max-reduction, the pivot
+//     row travels through LDS, the elimination is one FMA per entry and lane),
+//   * safeguarded iterative refinement (up to 3 steps) with the residual in OPERATOR form,
+//         r = f' - A'(w) - eps lam,     lam += (K + eps I)^-1 r,     w += A'^T dlam,
+//     where w is CARRIED (never recomputed from lam: the rounding of A'^T lam, |lam| ~ gamma scl^4
+//     |residual|, is what limits the plain dual form to 1e-10 on BASELINE config 1), and a final
+//     re-projection of w onto the boundary rows.
+// numpy prototype of exactly this arrangement: scripts/proto/dual_projected.py (float64, relative
+// L2 to the 60-digit minimiser: 1e-16 on config 1, <= 1e-12 at degree 32 / 64 points, 5e-12 where
+// n = M - 2 = 31 and the primal normal equations are at 3e-6).
 //
-// Accuracy gate: K is well conditioned when n + 2 <= M (few collocation points,
-// the regime the primal normal equations cannot resolve) and badly conditioned otherwise
-// (cond ~ |A A^T| / eps): there the primal solver is the accurate one (SURVEY.md App. B.3:
-// dual LU 1.8e-10 on config 1).  Limits: n <= 29, M <= 32, Poisson rows.
+// Mapping: LPE = 16 / 32 / 64 lanes per element (the smallest that holds max(n, M)), 64 / LPE
+// elements per wave, one wave per workgroup, wave-private LDS.  Lane r of an element is collocation
+// row r: it keeps its row of A' (M values) and its row of K (n values) in registers.
 #include "lssvr_device.hpp"
 #include "lssvr_kernels.hpp"
 #include "lssvr_wave.hpp"
@@ -21,176 +39,398 @@
 namespace lssvr {
 using namespace wave;
 
-template <int RHS>
-__global__ __launch_bounds__(kWavesPerBlock * 64, 2) void enhance_dual_kernel(EnhanceArgs p,
-                                                                              RecTables tb) {
-  __shared__ double2_t lds2[kWavesPerBlock * kWaveDoubles / 2];
-  double* const lds = reinterpret_cast<double*>(lds2);
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int c = lane & 31, h = lane >> 5;
-  double* const VtA = lds + wave * kWaveDoubles;
-  double* const VtB = VtA + kHalfDoubles;
-  double* const Vt = h ? VtB : VtA;
-  double* const Gb = Vt;
-  double* const Lm = Vt;
-  double* const Zs = Vt + kVDoubles;             // 32-entry broadcast vector
-  const int M = p.M, n = p.n;
-  const int NS = n + 2;                          // system size, <= 31
-  const bool need11 = NS > 16;
-  const int64_t npair = (p.ne + 1) >> 1;
+namespace {
 
-  for (int64_t pr = (int64_t)blockIdx.x * kWavesPerBlock + wave; pr < npair;
-       pr += (int64_t)gridDim.x * kWavesPerBlock) {
-    const int64_t e_raw = 2 * pr + h;
-    const bool live = e_raw < p.ne;
-    const int64_t e = live ? e_raw : p.ne - 1;
-    const double a = p.x[e];
-    const double b = p.x[e + 1];
-    const int64_t eg = e + p.elem_offset;
-    const double gl = (eg == 0 && a == p.gxmin) ? p.bc_left : p.u[e];
-    const double gr = (eg == p.ne_global - 1 && b == p.gxmax) ? p.bc_right : p.u[e + 1];
-    const DomainMap dm = map_params(a, b);
-    const double step = dm.oldlen / (double)(n - 1);
-    const double scl2 = dm.scl * dm.scl;
-    const double inv_scl2 = rcp_newton(scl2);
-    const double eps = rcp_newton(p.gamma * (scl2 * scl2));
+constexpr int kDualMaxM = 33;
+constexpr int kDualMaxN = 64;
+constexpr int kRefine = 3;
 
-    // ---- row c of Z: collocation point c (< n), boundary rows n, n+1, zero padding above ----
-    const bool is_pt = c < n;
-    const bool is_bc = (c == n) || (c == n + 1);
-    const double xk = linspace_at(a, b, dm.oldlen, step, is_pt ? c : 0, n);
-    const double xr = is_pt ? xk : (c == n ? a : b);
-    const double t = dm.off + dm.scl * xr;       // t_k, or t(xmin) / t(xmax) for the boundary rows
-    double rhs = 0.0;
-    if (is_pt) {
-      double fk;
-      if constexpr (RHS == LSSVR_RHS_SIN) fk = p.rhs_amp * sin_reduced(p.rhs_omega * xk);
-      else fk = p.rhs_values[e * n + c];
-      rhs = fk * inv_scl2;
-    } else if (c == n) {
-      rhs = gl;
-    } else if (c == n + 1) {
-      rhs = gr;
-    }
-    const double s_pt = is_pt ? -1.0 : 0.0;      // Ahat = -L''
-    const double s_bc = is_bc ? 1.0 : 0.0;
+// three-term recurrence coefficients as compile-time literals (the rows are built once per
+// element in straight-line code, so literals cost no long-lived registers):
+//   L_p = alL(p) t L_{p-1} - beL(p) L_{p-2};   q_m = L''_{m+2} = al2(m) t q_{m-1} - be2(m) q_{m-2};
+//   r_m = L'_{m+1} = al1(m) t r_{m-1} - be1(m) r_{m-2}
+__host__ __device__ constexpr double alL(int m) { return (double)(2 * m - 1) / (double)m; }
+__host__ __device__ constexpr double beL(int m) { return (double)(m - 1) / (double)m; }
+__host__ __device__ constexpr double al2(int m) { return (double)(2 * m + 3) / (double)m; }
+__host__ __device__ constexpr double be2(int m) { return (double)(m + 3) / (double)m; }
+__host__ __device__ constexpr double al1(int m) { return (double)(2 * m + 1) / (double)m; }
+__host__ __device__ constexpr double be1(int m) { return (double)(m + 1) / (double)m; }
 
-    // Z[c][pp] for pp = 0..M-1: value = s_pt * L''_pp(t) + s_bc * L_pp(t); `emit` consumes it
-    auto for_each_entry = [&](auto&& emit) {
-      double Lm2 = 1.0, Lm1 = t;                 // L_0, L_1
-      double q2 = 0.0, q1 = 0.0;                 // L''_{pp-2}, L''_{pp-1} seeds (L''_0 = L''_1 = 0)
-      emit(0, s_bc * 1.0);
-      if (M > 1) emit(1, s_bc * t);
-      for (int pp = 2; pp < M; ++pp) {
-        const double Lp = fma(tb.alL[pp] * t, Lm1, -(tb.beL[pp] * Lm2));
-        double q;
-        if (pp == 2) q = 3.0;
-        else if (pp == 3) q = 15.0 * t;
-        else q = fma(tb.al2[pp - 2] * t, q1, -(tb.be2[pp - 2] * q2));
-        emit(pp, fma(s_pt, q, s_bc * Lp));
-        Lm2 = Lm1;
-        Lm1 = Lp;
-        q2 = q1;
-        q1 = q;
-      }
-    };
+// per-element LDS (doubles).  ZS: rows of A' (row stride MP + 1, odd: conflict-free row writes),
+// later the transposed products for w = A'^T lam (row stride LPE + 1).
+template <int LPE, int MP>
+struct DualLds {
+  static constexpr int kZStride = MP + 1;
+  static constexpr int kTStride = LPE + 1;
+  static constexpr int kZS = (LPE * kZStride > MP * kTStride) ? LPE * kZStride : MP * kTStride;
+  static constexpr int kLa = kZS;                 // L_p(t_a), p < MP
+  static constexpr int kLb = kLa + MP;            // L_p(t_b)
+  static constexpr int kProw = kLb + MP;          // pivot row ring: 2 x (LPE + 2)  [.. , rhs]
+  static constexpr int kX = kProw + 2 * (LPE + 2);  // solution broadcast
+  static constexpr int kD = kX + LPE;             // equilibration scales
+  static constexpr int kW = kD + LPE;             // w (bubble part), p < MP
+  static constexpr int kSize = ((kW + MP + 1) / 2) * 2;
+};
 
-    wave_lds_sync();
-    for_each_entry([&](int pp, double v) { Vt[c * kSV + pp] = v; });
-    for (int pp = M; pp < kLP; ++pp) Vt[c * kSV + pp] = 0.0;
-    wave_lds_sync();
+// value of `v` in lane `src` (group-relative) of this lane's LPE-lane group
+template <int LPE>
+__device__ __forceinline__ double group_bcast(double v, int src, int gbase) {
+  if constexpr (LPE == 64) {
+    return readlane_f64(v, __builtin_amdgcn_readfirstlane(src));
+  } else {
+    return __shfl(v, gbase + src);
+  }
+}
 
-    // ---- K = Z Z^T on the matrix cores (contraction over the Legendre index) ----------------
-    double4_t accA00 = {0, 0, 0, 0}, accA10 = {0, 0, 0, 0}, accA11 = {0, 0, 0, 0};
-    double4_t accB00 = {0, 0, 0, 0}, accB10 = {0, 0, 0, 0}, accB11 = {0, 0, 0, 0};
-    {
-      const int ar = (lane & 15) * kSV + (lane >> 4);
+template <int LPE>
+__device__ __forceinline__ unsigned long long group_max_u64(unsigned long long k) {
 #pragma unroll
-      for (int s = 0; s < kLP / 4; ++s) {
-        const double a0 = VtA[ar + 4 * s];
-        const double b0 = VtB[ar + 4 * s];
-        accA00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, accA00, 0, 0, 0);
-        accB00 = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, b0, accB00, 0, 0, 0);
-        if (need11) {
-          const double a1 = VtA[ar + 16 * kSV + 4 * s];
-          const double b1 = VtB[ar + 16 * kSV + 4 * s];
-          accA10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a0, accA10, 0, 0, 0);
-          accB10 = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, b0, accB10, 0, 0, 0);
-          accA11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, accA11, 0, 0, 0);
-          accB11 = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, b1, accB11, 0, 0, 0);
+  for (int o = 1; o < LPE; o <<= 1) {
+    const unsigned long long other = __shfl_xor(k, o);
+    k = other > k ? other : k;
+  }
+  return k;
+}
+
+template <int LPE>
+__device__ __forceinline__ double group_sum(double v) {
+#pragma unroll
+  for (int o = 1; o < LPE; o <<= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+}  // namespace
+
+// LPE lanes per element, MP = padded number of Legendre coefficients (compile-time loop bound),
+// RHS as in the primal kernels, VC = variable-coefficient rows.
+template <int LPE, int MP, int RHS, bool VC>
+__global__ __launch_bounds__(64) void enhance_dual_kernel(EnhanceArgs p, int nrefine) {
+  using L = DualLds<LPE, MP>;
+  constexpr int EPW = 64 / LPE;
+  __shared__ double2_t lds2[EPW * L::kSize / 2];
+  const int lane = threadIdx.x & 63;
+  const int grp = lane / LPE, r = lane % LPE, gbase = grp * LPE;
+  double* const S = reinterpret_cast<double*>(lds2) + grp * L::kSize;
+  double* const Zs = S;
+  double* const LaS = S + L::kLa;
+  double* const LbS = S + L::kLb;
+  double* const Prow = S + L::kProw;
+  double* const Ds = S + L::kD;
+  double* const Ws = S + L::kW;
+  const int M = p.M, n = p.n;
+
+  const int64_t e_raw = (int64_t)blockIdx.x * EPW + grp;
+  const bool live = e_raw < p.ne;
+  const int64_t e = live ? e_raw : p.ne - 1;       // idle groups of the last wave: duplicate, stores masked
+  const double a = p.x[e];
+  const double b = p.x[e + 1];
+  const int64_t eg = e + p.elem_offset;
+  const double gl = (eg == 0 && a == p.gxmin) ? p.bc_left : p.u[e];
+  const double gr = (eg == p.ne_global - 1 && b == p.gxmax) ? p.bc_right : p.u[e + 1];
+  const double gamma = p.gamma_values ? p.gamma_values[e] : p.gamma;
+  const DomainMap dm = map_params(a, b);
+  const double step = dm.oldlen / (double)(n - 1);
+  const double scl2 = dm.scl * dm.scl;
+  const double inv_scl2 = rcp_newton(scl2);
+  const double eps = rcp_newton(gamma * (scl2 * scl2));
+
+  // ---- boundary rows B = [L_p(t_a); L_p(t_b)] -> LDS; Q = B B^T and its inverse ---------------
+  const double ta = dm.off + dm.scl * a;
+  const double tb_ = dm.off + dm.scl * b;
+  if (r < 2) {
+    const double t = r == 0 ? ta : tb_;
+    double* const dst = r == 0 ? LaS : LbS;
+    double Lm2 = 1.0, Lm1 = t;
+    dst[0] = 1.0;
+    if (MP > 1) dst[1] = (M > 1) ? t : 0.0;
+#pragma unroll
+    for (int pp = 2; pp < MP; ++pp) {
+      const double Lp = fma(alL(pp) * t, Lm1, -(beL(pp) * Lm2));
+      dst[pp] = (pp < M) ? Lp : 0.0;               // padding columns are zero
+      Lm2 = Lm1;
+      Lm1 = Lp;
+    }
+  }
+  wave_lds_sync();
+  double q00 = 0.0, q01 = 0.0, q11 = 0.0;
+#pragma unroll
+  for (int pp = 0; pp < MP; ++pp) {
+    const double la = LaS[pp], lb = LbS[pp];
+    q00 = fma(la, la, q00);
+    q01 = fma(la, lb, q01);
+    q11 = fma(lb, lb, q11);
+  }
+  const double qdet = rcp_newton(fma(q00, q11, -(q01 * q01)));
+  const double qi00 = q11 * qdet, qi01 = -q01 * qdet, qi11 = q00 * qdet;
+  const double g0 = fma(qi00, gl, qi01 * gr), g1 = fma(qi01, gl, qi11 * gr);   // (B B^T)^-1 g
+
+  // ---- row r of A: collocation point r (rows r >= n are padding: zero row, unit diagonal) ------
+  const bool is_pt = r < n;
+  const double xk = (is_pt && r == n - 1) ? b : (double)(is_pt ? r : 0) * step + a;
+  const double tk = dm.off + dm.scl * xk;
+  double ftil = 0.0;
+  if (is_pt) {
+    double fk;
+    if constexpr (RHS == LSSVR_RHS_SIN) fk = p.rhs_amp * sin_reduced(p.rhs_omega * xk);
+    else fk = p.rhs_values[e * n + r];
+    ftil = fk * inv_scl2;
+  }
+  double arow[MP];
+  {
+    const double sgn = is_pt ? -1.0 : 0.0;         // A = -L'' (padding rows: zero)
+    double ak = 1.0, bk = 0.0;
+    if constexpr (VC) {
+      if (is_pt) {
+        ak = p.a_values[e * n + r];
+        bk = p.da_values[e * n + r] * (0.5 * dm.oldlen);     // a'/scl
+      }
+    }
+    // q_m = L''_{m+2}, r1_m = L'_{m+1}
+    double q2 = 0.0, q1 = 0.0, r2 = 0.0, r1 = 0.0;
+#pragma unroll
+    for (int pp = 0; pp < MP; ++pp) {
+      double d2 = 0.0, d1 = 0.0;
+      if (pp >= 2) {
+        const int m = pp - 2;
+        d2 = (m == 0) ? 3.0 : (m == 1) ? 15.0 * tk : fma(al2(m) * tk, q1, -(be2(m) * q2));
+        q2 = q1;
+        q1 = d2;
+      }
+      if constexpr (VC) {
+        if (pp >= 1) {
+          const int m = pp - 1;
+          d1 = (m == 0) ? 1.0 : (m == 1) ? 3.0 * tk : fma(al1(m) * tk, r1, -(be1(m) * r2));
+          r2 = r1;
+          r1 = d1;
         }
       }
+      double v = VC ? fma(ak, d2, bk * d1) : d2;
+      arow[pp] = (pp < M) ? sgn * v : 0.0;
     }
-    wave_lds_sync();
-    {
-      const int col = lane & 15, rb = lane >> 4;
+  }
+  // projection A' = A - (A B^T)(B B^T)^-1 B and f' = f~ - A w_bc
+  double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int row = rb + 4 * q;
-        VtA[row * kSG + col] = accA00[q];
-        VtA[(16 + row) * kSG + col] = accA10[q];
-        VtA[col * kSG + 16 + row] = accA10[q];
-        VtA[(16 + row) * kSG + 16 + col] = accA11[q];
-        VtB[row * kSG + col] = accB00[q];
-        VtB[(16 + row) * kSG + col] = accB10[q];
-        VtB[col * kSG + 16 + row] = accB10[q];
-        VtB[(16 + row) * kSG + 16 + col] = accB11[q];
-      }
-    }
-    wave_lds_sync();
-    // + eps on the collocation block's diagonal (the "+ I/gamma"), rhs as row 31
-    Gb[c * kSG + c] += is_pt ? eps : 0.0;
-    Gb[kRhsRow * kSG + c] = rhs;           // row 31 of every column ...
-    Gb[c * kSG + kRhsRow] = rhs;           // ... and, symmetrically, column 31 (lane 31's column)
-    wave_lds_sync();
-    double col[kLP];
+  for (int pp = 0; pp < MP; ++pp) {
+    s0 = fma(arow[pp], LaS[pp], s0);
+    s1 = fma(arow[pp], LbS[pp], s1);
+  }
+  const double c0 = fma(qi00, s0, qi01 * s1), c1 = fma(qi01, s0, qi11 * s1);
 #pragma unroll
-    for (int i = 0; i < kLP; ++i) col[i] = Gb[i * kSG + c];
-    wave_lds_sync();
+  for (int pp = 0; pp < MP; ++pp) arow[pp] = fma(-c1, LbS[pp], fma(-c0, LaS[pp], arow[pp]));
+  const double fp = ftil - fma(s0, g0, s1 * g1);
 
-    bool piv_ok;
-    const double sol = ldlt_solve(col, Lm, Zs, c, NS, piv_ok);    // lam_c (c < n), mu (c = n, n+1)
-
-    // ---- w = Z^T [lam; mu]: contributions T[pp][c] = Z[c][pp] sol_c, then lane pp sums row pp -----
-    wave_lds_sync();
-    for_each_entry([&](int pp, double v) { Vt[pp * kSV + c] = v * sol; });
-    wave_lds_sync();
-    double w = 0.0;
-    if (c < M) {
+  // ---- K = A' A'^T: rows through LDS (broadcast reads), one dot product per entry ------------
 #pragma unroll
-      for (int i = 0; i < kLP; i += 2) {
-        const double2_t t2 = *reinterpret_cast<const double2_t*>(&Vt[c * kSV + i]);
-        w += t2[0];
-        w += t2[1];
+  for (int pp = 0; pp < MP; ++pp) Zs[r * L::kZStride + pp] = arow[pp];
+  wave_lds_sync();
+  double krow[LPE];
+#pragma unroll
+  for (int c = 0; c < LPE; ++c) {
+    double acc = 0.0;
+    if (c < n) {
+      const double* __restrict__ zc = Zs + c * L::kZStride;
+#pragma unroll
+      for (int pp = 0; pp < MP; ++pp) acc = fma(arow[pp], zc[pp], acc);
+    }
+    krow[c] = acc;
+  }
+  // (K + eps I), Jacobi equilibration
+  double dr = 1.0;
+#pragma unroll
+  for (int c = 0; c < LPE; ++c)
+    if (c == r) {
+      const double kd = is_pt ? krow[c] + eps : 1.0;
+      krow[c] = kd;
+      dr = is_pt ? rsqrt_newton(kd) : 1.0;
+    }
+  Ds[r] = dr;
+  wave_lds_sync();       // (also: every lane is done reading Zs)
+#pragma unroll
+  for (int c = 0; c < LPE; ++c) krow[c] = (c < n && is_pt) ? krow[c] * dr * Ds[c] : ((c == r) ? 1.0 : 0.0);
+
+  // ---- LU with partial pivoting, rhs carried; refinement re-uses the factors -------------------
+  // pivstep: step at which this row was the pivot (-1: still active).  After the elimination the
+  // row holds U[pivstep][c] for c >= pivstep and the multipliers L for c < pivstep.
+  int pivstep = is_pt ? -1 : 0x7fff;
+  double rinv_own = 1.0;
+  int pvec = 0;                                    // lane j of the group keeps the pivot lane of step j
+  double y = dr * fp;
+  // Only the STEPS are guarded by n (uniform branches); inside a step every one of the LPE columns
+  // is processed: columns >= n are exact zeros in every row (padding), so they stay zero, and
+  // guarding each column made the LPE = 64 kernel 63 000 instructions long (long-branch
+  // expansion, hundreds of spilled SGPRs -- and wrong results from that build).
+  // (ns: an opaque copy of n per use -- otherwise hipcc hoists the LPE uniform conditions j < n
+  // out of the refinement loop and spills them)
+  auto eliminate = [&]() {
+    int ns = n;
+    asm volatile("" : "+s"(ns));
+#pragma unroll
+    for (int j = 0; j < LPE; ++j) {
+      if (j < ns) {
+        const bool active = pivstep < 0;
+        unsigned long long key = 0;
+        if (active)
+          key = (__builtin_bit_cast(unsigned long long, fabs(krow[j])) & ~127ull) | 64ull | (unsigned)r;
+        key = group_max_u64<LPE>(key);
+        const int P = (int)(key & 63ull);
+        double* const pr = Prow + (j & 1) * (LPE + 2);
+        if (r == P) {
+#pragma unroll
+          for (int c = j; c < LPE; ++c) pr[c] = krow[c];
+          pr[LPE] = y;
+          pivstep = j;
+        }
+        if (r == j) pvec = P;
+        wave_lds_sync();
+        const double rinv = rcp_newton(pr[j]);
+        if (r == P) rinv_own = rinv;
+        const bool act = pivstep < 0;
+        const double m = act ? krow[j] * rinv : 0.0;
+#pragma unroll
+        for (int c = j + 1; c < LPE; ++c) krow[c] = fma(-m, pr[c], krow[c]);
+        y = fma(-m, pr[LPE], y);
+        krow[j] = act ? m : krow[j];
       }
     }
-    const double bad = half_sum((fabs(w) < 1.0e300) ? 0.0 : 1.0);
-    const bool ok = piv_ok && (bad == 0.0);
-    if (live) {
-      double* const Wrow = p.W + e * M;
-      double out = w;
-      if (!ok) out = (c == 0) ? 0.5 * (gl + gr) : (c == 1) ? 0.5 * (gr - gl) : 0.0;
-      if (c < M) Wrow[c] = out;
-      if (c == 0) {
-        if (p.status) p.status[e] = ok ? LSSVR_ST_OK : LSSVR_ST_FALLBACK;
-        if (!ok && p.fail_count) atomicAdd(p.fail_count, 1);
+  };
+  // forward substitution with the stored multipliers (refinement): v -> L^-1 P v, row-indexed
+  auto forward = [&](double v) -> double {
+    int ns = n;
+    asm volatile("" : "+s"(ns));
+#pragma unroll
+    for (int j = 0; j < LPE; ++j) {
+      if (j < ns) {
+        const int P = __shfl(pvec, gbase + j);
+        const double vj = group_bcast<LPE>(v, P, gbase);
+        const double m = (pivstep > j && pivstep < 0x7fff) ? krow[j] : 0.0;
+        v = fma(-m, vj, v);
       }
+    }
+    return v;
+  };
+  // back substitution U x = v; returns x_r (column-indexed: lane r gets the unknown of column r)
+  auto backward = [&](double v) -> double {
+    double xr = 0.0;
+    int ns = n;
+    asm volatile("" : "+s"(ns));
+#pragma unroll
+    for (int j = LPE - 1; j >= 0; --j) {
+      if (j < ns) {
+        const int P = __shfl(pvec, gbase + j);
+        const double xj = group_bcast<LPE>(v * rinv_own, P, gbase);     // lane P: pivstep == j
+        if (r == j) xr = xj;
+        const double u = (pivstep < j) ? krow[j] : 0.0;
+        v = fma(-u, xj, v);
+      }
+    }
+    return xr;
+  };
+  // dw_p = sum_r A'[r][p] dl_r for p < MP -> lane p (LPE >= M); through LDS, row stride LPE + 1
+  auto at_times = [&](double dl) -> double {
+    wave_lds_sync();
+#pragma unroll
+    for (int pp = 0; pp < MP; ++pp) Zs[pp * L::kTStride + r] = arow[pp] * dl;
+    wave_lds_sync();
+    double acc = 0.0;
+    if (r < MP) {
+      const double* __restrict__ row = Zs + r * L::kTStride;
+#pragma unroll
+      for (int c = 0; c < LPE; ++c) acc += row[c];        // (padding rows contribute exact zeros)
+    }
+    return acc;
+  };
+
+  eliminate();
+  double lam = dr * backward(y);                   // unscale: lam = D x
+  if (!is_pt) lam = 0.0;
+  double wv = at_times(lam);                       // lane p: bubble part of w_p (carried)
+  // equilibrated residual of the pair (lam, w) in operator form, and its squared norm
+  auto residual = [&](double lam_, double wv_, double& nrm) -> double {
+    wave_lds_sync();
+    if (r < MP) Ws[r] = wv_;
+    wave_lds_sync();
+    // f' - eps lam - A' w in compensated (double-double) arithmetic: the terms are ~|A'| |w| while
+    // the residual of a converged pair is ~eps |lam|; with a plain float64 sum the refinement stalls
+    // at ~u |A'| / sqrt(eps) (1e-10 at gamma scl^4 ~ 1e15), with error-free products and sums at ~u.
+    double hi = fp, lo = 0.0;
+    auto acc = [&](double x, double y) {          // (hi, lo) += x * y exactly
+      const double pr_ = x * y;
+      const double pe = fma(x, y, -pr_);
+      const double t = hi + pr_;
+      const double bb = t - hi;
+      lo += ((hi - (t - bb)) + (pr_ - bb)) + pe;
+      hi = t;
+    };
+    acc(-eps, lam_);
+#pragma unroll
+    for (int pp = 0; pp < MP; ++pp) acc(-arow[pp], Ws[pp]);
+    double res = hi + lo;
+    res = is_pt ? dr * res : 0.0;
+    nrm = group_sum<LPE>(res * res);
+    return res;
+  };
+  // Safeguarded refinement: a step is kept only if it lowers the residual norm.  On coarse meshes
+  // at degree 32 (cond ~ 1e21) the factors are noise in the near-null directions of K and an
+  // unguarded step can amplify rounding in A'^T dlam (measured: 4e-12 -> 2e-7 -> 1e-2 over four
+  // unguarded steps on one element of the 24-element fixture mesh; every other element improves).
+  double nrm = 0.0;
+  double res = residual(lam, wv, nrm);
+#pragma unroll 1
+  for (int it = 0; it < nrefine; ++it) {
+    double dl = dr * backward(forward(res));
+    if (!is_pt) dl = 0.0;
+    const double lam_c = lam + dl;
+    const double wv_c = wv + at_times(dl);
+    double nrm_c = 0.0;
+    const double res_c = residual(lam_c, wv_c, nrm_c);
+    const bool better = nrm_c < 4.0 * nrm;       // (NaN: rejected; a step may raise the norm 2x: at the
+                                                 // rounding floor the norm is noise, a diverging step gains 100x)
+    lam = better ? lam_c : lam;
+    wv = better ? wv_c : wv;
+    res = better ? res_c : res;
+    nrm = better ? nrm_c : nrm;
+  }
+  // ---- w = w_bc + w', re-projected onto the boundary rows -------------------------------------
+  double wp = 0.0;
+  if (r < MP) wp = fma(LaS[r], g0, fma(LbS[r], g1, wv));
+  const double ra = group_sum<LPE>((r < MP) ? LaS[r] * wp : 0.0) - gl;      // B w - g
+  const double rb = group_sum<LPE>((r < MP) ? LbS[r] * wp : 0.0) - gr;
+  const double k0 = fma(qi00, ra, qi01 * rb), k1 = fma(qi01, ra, qi11 * rb);
+  if (r < MP) wp = fma(-k1, LbS[r], fma(-k0, LaS[r], wp));
+  const double bad = group_sum<LPE>((r < M && !(fabs(wp) < 1.0e300)) ? 1.0 : 0.0);
+  const bool ok = bad == 0.0;
+  if (live) {
+    double* const Wrow = p.W + e * (p.ldw ? p.ldw : (int64_t)M);
+    double out = wp;
+    if (!ok) out = (r == 0) ? 0.5 * (gl + gr) : (r == 1) ? 0.5 * (gr - gl) : 0.0;
+    if (r < M) Wrow[r] = out;
+    if (r == 0) {
+      if (p.status) p.status[e] = ok ? LSSVR_ST_OK : LSSVR_ST_FALLBACK;
+      if (!ok && p.fail_count) atomicAdd(p.fail_count, 1);
     }
   }
 }
 
-hipError_t enhance_dual(const EnhanceArgs& a, hipStream_t s, const LaunchOpts* o) {
-  if (a.M > kLP || a.n + 2 > kRhsRow || a.a_values) return hipErrorInvalidValue;
-  static const RecTables tables = make_rec_tables();
-  const int64_t npair = (a.ne + 1) / 2;
-  int64_t blocks = (npair + kWavesPerBlock - 1) / kWavesPerBlock;
-  const int64_t cap = 256 * 2 * 8;
-  if (blocks > cap) blocks = cap;
-  const dim3 grid((unsigned)blocks), block(kWavesPerBlock * 64);
+template <int LPE, int MP>
+static hipError_t launch_dual(const EnhanceArgs& a, hipStream_t s, const LaunchOpts* o) {
+  constexpr int EPW = 64 / LPE;
+  const int64_t blocks = (a.ne + EPW - 1) / EPW;
+  if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+  const dim3 grid((unsigned)blocks), block(64);
+  const int nref = kRefine;
+  if (a.a_values) return launch(enhance_dual_kernel<LPE, MP, LSSVR_RHS_ARRAY, true>, grid, block, s, o, a, nref);
   if (a.rhs_id == LSSVR_RHS_SIN)
-    return launch(enhance_dual_kernel<LSSVR_RHS_SIN>, grid, block, s, o, a, tables);
-  return launch(enhance_dual_kernel<LSSVR_RHS_ARRAY>, grid, block, s, o, a, tables);
+    return launch(enhance_dual_kernel<LPE, MP, LSSVR_RHS_SIN, false>, grid, block, s, o, a, nref);
+  return launch(enhance_dual_kernel<LPE, MP, LSSVR_RHS_ARRAY, false>, grid, block, s, o, a, nref);
+}
+
+hipError_t enhance_dual(const EnhanceArgs& a, hipStream_t s, const LaunchOpts* o) {
+  if (a.M > kDualMaxM || a.n > kDualMaxN || a.elem_ids) return hipErrorInvalidValue;
+  const int need = a.n > a.M ? a.n : a.M;
+  if (need <= 16) return launch_dual<16, 16>(a, s, o);
+  if (need <= 32) return launch_dual<32, 32>(a, s, o);
+  return launch_dual<64, 36>(a, s, o);
 }
 
 }  // namespace lssvr

@@ -46,16 +46,17 @@ extern "C" {
                                `amp * np.sin(omega * x)`; Poisson: p = {pi^2, pi} */
 
 /* per-element solver */
-#define LSSVR_SOLVER_PRIMAL 0 /* BC-eliminated primal normal equations, (M-2) SPD,
-                                 Cholesky (default; <=1e-15 of the exact minimiser on
-                                 every BASELINE config).  When n_colloc < M-2 the primal
-                                 Gram is rank deficient and the call is routed to
-                                 LSSVR_SOLVER_DUAL (its limits then apply)         */
-#define LSSVR_SOLVER_DUAL   1 /* north_star's dual Gram form: K = Z Z^T + I/gamma over the
-                                 n collocation + 2 boundary rows, (n+2) LDL^T solve, w = Z^T
-                                 alpha.  n_colloc <= 29, M <= 32.  Accurate when n+2 <= M
-                                 (where PRIMAL is rank deficient); accuracy-gated otherwise,
-                                 see DESIGN.md                                          */
+#define LSSVR_SOLVER_PRIMAL 0 /* BC-eliminated primal normal equations, (M-2) SPD, LDL^T
+                                 (default; <=1e-15 of the exact minimiser on every BASELINE
+                                 config).  When n_colloc < M-2 the primal Gram is rank
+                                 deficient and the call is routed to LSSVR_SOLVER_DUAL (its
+                                 limits then apply)                                      */
+#define LSSVR_SOLVER_DUAL   1 /* north_star's dual Gram form (K + I/gamma) alpha = y: kernel
+                                 Gram matrix of the collocation rows (boundary rows eliminated
+                                 as a 2x2 block pivot), Jacobi-equilibrated, LU with partial
+                                 pivoting, two steps of iterative refinement.  n_colloc <= 64,
+                                 M <= 33, Poisson and variable-coefficient rows.  <= 1e-12 of
+                                 the exact minimiser on every BASELINE config  */
 #define LSSVR_SOLVER_PRIMAL_WAVE 2 /* same algorithm as PRIMAL, forced onto the
                                  wave-per-element / f64-MFMA Gram mapping whatever M is
                                  (PRIMAL picks lane-per-element for M <= 22); for A/B
@@ -125,7 +126,9 @@ int lssvr_enhance_profiled(const double* x, const double* u, int64_t ne,
  * lssvr_step -- one whole step of the hot path on one mesh shard in ONE launch:
  * lssvr_p1_assemble (in-kernel rhs, nquad-point Gauss) + lssvr_enhance (primal
  * solver, in-kernel rhs).  For M <= 22 the two run as disjoint block ranges of a single
- * grid; arguments as in the two separate calls.
+ * grid; arguments as in the two separate calls.  PRIMAL SOLVER ONLY: n_colloc < M-2 (rank-
+ * deficient primal normal equations) returns LSSVR_ERR_SOLVER -- use lssvr_p1_assemble +
+ * lssvr_enhance, which routes that regime to the dual solver.
  */
 int lssvr_step(const double* x, const double* u, int64_t ne,
                int64_t elem_offset, int64_t ne_global,
@@ -140,6 +143,7 @@ int lssvr_step(const double* x, const double* u, int64_t ne,
  *   -a_k (2/h)^2 L_p''(t_k) - da_k (2/h) L_p'(t_k),
  * with a_values/da_values/rhs_values tabulated at the collocation points
  * ([ne*n_colloc], row-major per element).  Other arguments as lssvr_enhance.
+ * n_colloc < M-2 is routed to the dual solver (n_colloc <= 64), like lssvr_enhance.
  */
 int lssvr_enhance_varcoef(const double* x, const double* u, int64_t ne,
                           int64_t elem_offset, int64_t ne_global,

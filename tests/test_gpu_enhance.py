@@ -289,10 +289,11 @@ def test_enhance_sharded_single_rank_chunks(dev):
     assert Wg is None and torch.equal(Wl, Wref)
 
 
-def test_step_and_varcoef_refuse_rank_deficient_primal(dev):
+def test_step_refuses_rank_deficient_primal(dev):
     """n_colloc < M-2: the BC-eliminated primal Gram is rank deficient and float64 returns O(1)
-    errors with status OK (oracle: 2.06 relative at M=17, n=12).  lssvr_enhance reroutes to the
-    dual solver; lssvr_step and lssvr_enhance_varcoef have no such route and must refuse."""
+    errors with status OK (oracle: 2.06 relative at M=17, n=12).  lssvr_enhance and
+    lssvr_enhance_varcoef reroute to the dual solver (tests/test_gpu_enhance_dual.py); the fused
+    lssvr_step is primal-only and must refuse."""
     import torch
     from hybrid_fem_lssvr_amd import ops, _capi
     nodes = np.linspace(-1, 1, 25)
@@ -300,13 +301,17 @@ def test_step_and_varcoef_refuse_rank_deficient_primal(dev):
     plan = ops.StepPlan(x, u, 17, 1e4, 12, global_domain=(-1.0, 1.0))
     with pytest.raises(_capi.LssvrHipError, match="rank deficient"):
         plan.launch()
-    z = torch.ones((24, 12), dtype=torch.float64, device=dev)
-    with pytest.raises(_capi.LssvrHipError, match="rank deficient"):
-        ops.enhance_varcoef(x, u, 17, 1e4, 12, z, z.clone(), z.clone(), global_domain=(-1.0, 1.0))
-    # the boundary of the regime (n == M-2) is accepted by both
+    # the boundary of the regime (n == M-2) is accepted
     ops.StepPlan(x, u, 14, 1e4, 12, global_domain=(-1.0, 1.0)).launch()
-    ops.enhance_varcoef(x, u, 14, 1e4, 12, z, z.clone(), z.clone(), global_domain=(-1.0, 1.0))
     torch.cuda.synchronize()
+    # the rerouted call is exact where the primal solver would be O(1) wrong
+    W, st = ops.enhance(x, u, 17, 1e4, 12, global_domain=(-1.0, 1.0))
+    torch.cuda.synchronize()
+    assert int(st.sum()) == 0
+    if cf.HAVE_MP:
+        sel = [0, 11, 23]
+        tr = cf.truth_all(nodes, np.sin(np.pi * nodes), 17, 1e4, 12, orc.poisson_rhs, (-1.0, 1.0), sel)
+        assert orc.rel_l2_coef(W.cpu().numpy()[sel], tr).max() <= 1e-13
 
 
 @pytest.mark.parametrize("n", [257, 1024, 4096])
