@@ -94,6 +94,10 @@ int enhance_dispatch(const lssvr::EnhanceArgs& a, int solver_id, hipStream_t s,
   }
   if (a.M <= lssvr::kSmallMaxM && solver_id == LSSVR_SOLVER_PRIMAL)
     return check_launch(lssvr::enhance_small(a, s, o), "enhance_small");
+  // large degree: Poisson rows take the Chebyshev-moment kernel; variable-coefficient rows and
+  // LSSVR_SOLVER_PRIMAL_WAVE the direct Gram on the f64 matrix cores
+  if (solver_id == LSSVR_SOLVER_PRIMAL && !a.a_values)
+    return check_launch(lssvr::enhance_large_cheb(a, s, o), "enhance_large_cheb");
   return check_launch(lssvr::enhance_large(a, s, o), "enhance_large");
 }
 }  // namespace
@@ -192,7 +196,7 @@ int lssvr_step(const double* x, const double* u, int64_t ne, int64_t elem_offset
   // large degree: the enhancement is long enough that a fused launch buys nothing
   rc = check_launch(lssvr::p1_assemble(p, s), "p1_assemble");
   if (rc != LSSVR_OK) return rc;
-  return check_launch(lssvr::enhance_large(a, s), "enhance_large");
+  return check_launch(lssvr::enhance_large_cheb(a, s), "enhance_large_cheb");
 }
 
 int lssvr_enhance_varcoef(const double* x, const double* u, int64_t ne, int64_t elem_offset,
@@ -255,7 +259,7 @@ int lssvr_enhance_subset(const double* x, const double* u, int64_t ne_mesh,
   if (nsub == 0) return LSSVR_OK;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (M <= lssvr::kSmallMaxM) return check_launch(lssvr::enhance_small(a, s), "enhance_small(subset)");
-  return check_launch(lssvr::enhance_large(a, s), "enhance_large(subset)");
+  return check_launch(lssvr::enhance_large_cheb(a, s), "enhance_large_cheb(subset)");
 }
 
 int lssvr_enhance_shared(const double* x, const double* u, int64_t ne, int64_t elem_offset,
