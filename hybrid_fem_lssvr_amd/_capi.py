@@ -23,6 +23,7 @@ RHS_SIN = 1
 SOLVER_PRIMAL = 0
 SOLVER_DUAL = 1
 SOLVER_PRIMAL_WAVE = 2
+SOLVER_PRIMAL_MOMENT = 3
 ST_OK = 0
 ST_FALLBACK = 1
 

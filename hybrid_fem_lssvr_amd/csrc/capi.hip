@@ -94,10 +94,15 @@ int enhance_dispatch(const lssvr::EnhanceArgs& a, int solver_id, hipStream_t s,
   }
   if (a.M <= lssvr::kSmallMaxM && solver_id == LSSVR_SOLVER_PRIMAL)
     return check_launch(lssvr::enhance_small(a, s, o), "enhance_small");
-  // large degree: Poisson rows take the Chebyshev-moment kernel; variable-coefficient rows and
-  // LSSVR_SOLVER_PRIMAL_WAVE the direct Gram on the f64 matrix cores
-  if (solver_id == LSSVR_SOLVER_PRIMAL && !a.a_values)
+  if (a.elem_ids && solver_id != LSSVR_SOLVER_PRIMAL)
+    return fail(LSSVR_ERR_SOLVER, "subset launches take LSSVR_SOLVER_PRIMAL");
+  // large degree: the direct Gram on the f64 matrix cores; the Chebyshev-moment wave kernel (half
+  // the instructions, but 2 resident waves per SIMD instead of 3: 10-20 % slower, DESIGN.md
+  // section 9) only on request
+  if (solver_id == LSSVR_SOLVER_PRIMAL_MOMENT) {
+    if (a.a_values) return fail(LSSVR_ERR_SOLVER, "LSSVR_SOLVER_PRIMAL_MOMENT: Poisson rows only");
     return check_launch(lssvr::enhance_large_cheb(a, s, o), "enhance_large_cheb");
+  }
   return check_launch(lssvr::enhance_large(a, s, o), "enhance_large");
 }
 }  // namespace
@@ -122,7 +127,7 @@ int lssvr_enhance(const double* x, const double* u, int64_t ne, int64_t elem_off
   a.status = status;
   a.fail_count = fail_count;
   if (solver_id != LSSVR_SOLVER_PRIMAL && solver_id != LSSVR_SOLVER_DUAL &&
-      solver_id != LSSVR_SOLVER_PRIMAL_WAVE)
+      solver_id != LSSVR_SOLVER_PRIMAL_WAVE && solver_id != LSSVR_SOLVER_PRIMAL_MOMENT)
     return fail(LSSVR_ERR_SOLVER, "unknown solver_id %d", solver_id);
   if (ne == 0) return LSSVR_OK;
   return enhance_dispatch(a, solver_id, reinterpret_cast<hipStream_t>(stream), nullptr);
@@ -143,7 +148,7 @@ int lssvr_enhance_profiled(const double* x, const double* u, int64_t ne, int64_t
   if (rc != LSSVR_OK) return rc;
   a.status = status;
   if (solver_id != LSSVR_SOLVER_PRIMAL && solver_id != LSSVR_SOLVER_DUAL &&
-      solver_id != LSSVR_SOLVER_PRIMAL_WAVE)
+      solver_id != LSSVR_SOLVER_PRIMAL_WAVE && solver_id != LSSVR_SOLVER_PRIMAL_MOMENT)
     return fail(LSSVR_ERR_SOLVER, "unknown solver_id %d", solver_id);
   lssvr::LaunchOpts o;
   if (hipEventCreate(&o.start) != hipSuccess || hipEventCreate(&o.stop) != hipSuccess)
@@ -196,7 +201,7 @@ int lssvr_step(const double* x, const double* u, int64_t ne, int64_t elem_offset
   // large degree: the enhancement is long enough that a fused launch buys nothing
   rc = check_launch(lssvr::p1_assemble(p, s), "p1_assemble");
   if (rc != LSSVR_OK) return rc;
-  return check_launch(lssvr::enhance_large_cheb(a, s), "enhance_large_cheb");
+  return check_launch(lssvr::enhance_large(a, s), "enhance_large");
 }
 
 int lssvr_enhance_varcoef(const double* x, const double* u, int64_t ne, int64_t elem_offset,
@@ -259,7 +264,7 @@ int lssvr_enhance_subset(const double* x, const double* u, int64_t ne_mesh,
   if (nsub == 0) return LSSVR_OK;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (M <= lssvr::kSmallMaxM) return check_launch(lssvr::enhance_small(a, s), "enhance_small(subset)");
-  return check_launch(lssvr::enhance_large_cheb(a, s), "enhance_large_cheb(subset)");
+  return check_launch(lssvr::enhance_large(a, s), "enhance_large(subset)");
 }
 
 int lssvr_enhance_shared(const double* x, const double* u, int64_t ne, int64_t elem_offset,

@@ -19,14 +19,21 @@
 //     instructions per point, no cross-lane traffic in the loop.  Two xor-shuffles combine the four
 //     slices; the 92 numbers per element go to LDS.  The phase is the same for every M (degree 30
 //     always: the padding costs nothing that the old 32-column padding did not).
-//   Phase 2 (solve), 8 rounds of two elements: lane (c = lane & 31, h = lane >> 5) builds column c
-//     of  S2 = m_{i+c} + m_{|i-c|} + 2 eps (N + C_z^T C_z)  straight from the moments (two
-//     conflict-free LDS reads, one table load and four FMAs per entry; first-order boundary rows
-//     and compile-time ridge tables as in the lane kernel), the right-hand side rides along as
-//     row / column 31, then the DPP-broadcast LDL^T of lssvr_wave.hpp (factor frozen in registers),
-//     back-substitution, v = Y z through LDS, w_{0,1} by half-wave reductions.
-// No MFMA, no operand staging, no accumulator transposition: the LDS traffic of the old front end
-// (35 % of its LDS cycles were bank conflicts) is gone with it.
+//   Phase 2 (solve), rounds of FOUR elements: lane (g = lane >> 4, q = lane & 15) builds columns q
+//     and q + 16 of  S2 = m_{i+c} + m_{|i-c|} + 2 eps (N + C_z^T C_z)  straight from the moments
+//     (two conflict-free LDS reads, one table load and four FMAs per entry; first-order boundary
+//     rows and compile-time ridge tables as in the lane kernel), the right-hand side rides along
+//     as row / column 31, then the four-systems-per-wave DPP-broadcast LDL^T of lssvr_wave.hpp
+//     (16 lanes per system, two columns per lane, factor frozen in registers, no LDS, no
+//     cross-row permutes), DPP back-substitution, v = Y z through LDS, w_{0,1} by row reductions.
+// No MFMA, no operand staging, no accumulator transposition -- and half the instructions of
+// enhance_large.hip (880 against 980 vector + 160 matrix instructions per element).  MEASURED
+// (MI355X, M = 33, 64 points): 407-465 us at 1e5 elements and 3.3-3.9 ms at 1e6 against 352-387 us
+// and 3.2 ms: the 128 registers of the two-columns-per-lane factorisation leave 2 resident waves
+// per SIMD where enhance_large.hip runs 3, and a wave of these dependent FP64 / DPP chains issues
+// one instruction per 16-20 cycles whatever the kernel (rocprofv3: 50 % of the wave-cycles in
+// s_waitcnt at 2 waves against 23 % at 3).  It is therefore an opt-in solver
+// (LSSVR_SOLVER_PRIMAL_MOMENT), kept for the A/B; DESIGN.md section 9 has the numbers.
 #include "cheb_tables.hpp"
 #include "lssvr_device.hpp"
 #include "lssvr_kernels.hpp"
@@ -38,15 +45,34 @@ using namespace wave;
 
 namespace {
 
-constexpr int kEPW = 16;                 // elements per wave
+constexpr int kEPW = 16;                 // elements per wave (measured: 8 per wave, with three-step slice
+                                         // reductions, is 16 % slower at 1e5 elements and 30 % at 1e6)
+constexpr int kSlices = 64 / kEPW;       // phase 1: lanes (= point slices) per element
+constexpr int kSliceShift = 2;
+static_assert((1 << kSliceShift) == kSlices, "slice shift");
 constexpr int kReseedLarge = 64;         // rotation-carried rhs: re-seeded every 64 points of a slice
 constexpr int kTop = 30;                 // highest Chebyshev degree of a row (M = 33)
-constexpr int kMomStride = 64;           // m_0 .. m_60 (+ 3 pad)
-constexpr int kRStride = 32;             // r_0 .. r_30 (+ 1 pad)
+// m_0 .. m_60 of an element; stride 80 doubles = 160 banks: the two 16-lane groups that share a
+// 32-lane half of a ds_read_b64 land on disjoint bank halves (stride 64 was a 2-way conflict)
+constexpr int kMomStride = 80;
+constexpr int kRStride = 48;             // r_0 .. r_30, same rule (96 banks = 32 mod 64)
 constexpr int kMomDoubles = kEPW * kMomStride;
 constexpr int kRDoubles = kEPW * kRStride;
-constexpr int kHalfDoubles2 = 3 * 64;    // per half: E (C rows, 64) | F (C_z rows, 64) | Z (64)
-constexpr int kLdsDoubles = kMomDoubles + kRDoubles + 2 * kHalfDoubles2;
+constexpr int kNDoubles = 0;             // (N = Y^T Y is read from the L1-resident device table)
+constexpr int kQuarterDoubles = 64;      // per 16-lane row: Z (z for v = Y z; entries [32, 64) stay 0)
+constexpr int kLdsDoubles = kMomDoubles + kRDoubles + kNDoubles + 4 * kQuarterDoubles;
+
+// LDS accumulate (ds_add_f64, no return value)
+__device__ __forceinline__ void lds_add(double* addr, double v) {
+  __hip_atomic_fetch_add(addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// sum over the 16 lanes of a DPP row
+__device__ __forceinline__ double row_sum16(double v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
 
 // zero-padded device copies of the constant tables for run-time indexed reads
 struct ChebDeviceTables {
@@ -91,7 +117,7 @@ __global__ __launch_bounds__(64, 2) void enhance_large_cheb_kernel(EnhanceArgs p
 
   // =========================== phase 1: moments ============================================
   {
-    const int i1 = lane >> 2, s = lane & 3;
+    const int i1 = lane >> kSliceShift, s = lane & (kSlices - 1);
     const int64_t e1 = (E0 + i1 < p.ne) ? E0 + i1 : p.ne - 1;     // tail: duplicates (never stored)
     int64_t id = e1;
     if (p.elem_ids) {
@@ -105,141 +131,147 @@ __global__ __launch_bounds__(64, 2) void enhance_large_cheb_kernel(EnhanceArgs p
     const double hh = 0.5 * dm.oldlen;
     const double inv_scl2 = hh * hh;                              // 1 / scl^2 within 2 ulp
 
-    double mom[kTop + 1], sq[15], nb[15], rr[kTop + 1];
+    // zero the wave's accumulation area (slices add into it with LDS atomics below)
 #pragma unroll
-    for (int d = 0; d <= kTop; ++d) mom[d] = rr[d] = 0.0;
-#pragma unroll
-    for (int j = 0; j < 15; ++j) sq[j] = nb[j] = 0.0;
+    for (int t = 0; t < (kMomDoubles + kRDoubles + 63) / 64; ++t)
+      if (t * 64 + lane < kMomDoubles + kRDoubles) lds[t * 64 + lane] = 0.0;
+    wave_lds_sync();
+    double* const mo = Mom + i1 * kMomStride;
+    double* const ro = Rv + i1 * kRStride;
 
+    // Two passes over the slice's points, so that neither holds more than 61 accumulators (one pass
+    // with all 91 pushed the kernel over 256 VGPRs: 190 spilled registers, reloaded in the solve
+    // rounds -- the waves spent half their life in s_waitcnt): pass 0 = moments m_1..m_30 and the
+    // right-hand side, pass 1 = the squares / neighbour products of the upper moments.  The
+    // abscissae and the T recurrence are recomputed (29 FMAs per point, +4 % instructions).
     double rs = 0.0, rc = 1.0, sd = 0.0, cd = 1.0, th0 = 0.0, dth4 = 0.0, kappa = 0.0;
     if constexpr (RHS == LSSVR_RHS_SIN) {
-      dth4 = 4.0 * (p.rhs_omega * step);
+      dth4 = (double)kSlices * (p.rhs_omega * step);            // angle between a slice's points
       sincos_tab(dth4, sd, cd, p.trig);
       kappa = -2.0 * (p.rhs_amp * inv_scl2);                      // phi2 = -2 f / scl^2
     }
     [[maybe_unused]] const double fscale = -2.0 * inv_scl2;
-    const int iters = (n + 3) >> 2;
-    for (int j0 = 0; j0 < iters; j0 += kReseedLarge) {
-      if constexpr (RHS == LSSVR_RHS_SIN) {
-        const double x0 = fma((double)(s + 4 * j0), step, a);
-        th0 = p.rhs_omega * x0;
-        sincos_tab(th0, rs, rc, p.trig);
-        rs *= kappa;
-        rc *= kappa;
+    const int iters = (n + kSlices - 1) >> kSliceShift;
+    {
+      double mom[kTop + 1], rr[kTop + 1];
+#pragma unroll
+      for (int d = 0; d <= kTop; ++d) mom[d] = rr[d] = 0.0;
+      for (int j0 = 0; j0 < iters; j0 += kReseedLarge) {
+        if constexpr (RHS == LSSVR_RHS_SIN) {
+          const double x0 = fma((double)(s + kSlices * j0), step, a);
+          th0 = p.rhs_omega * x0;
+          sincos_tab(th0, rs, rc, p.trig);
+          rs *= kappa;
+          rc *= kappa;
+        }
+        const int j1 = min(j0 + kReseedLarge, iters);
+        for (int j = j0; j < j1; ++j) {
+          const int k = s + kSlices * j;
+          const bool valid = k < n;
+          // np.linspace / mapdomain, two roundings each; last point = b
+          const double xk = (k == n - 1) ? b : (double)k * step + a;
+          const double tk = dm.off + dm.scl * xk;
+          double phi2;
+          if constexpr (RHS == LSSVR_RHS_SIN) {
+            const double arg = p.rhs_omega * xk;
+            const double delta = fma(-(double)(j - j0), dth4, arg - th0);
+            phi2 = fma(rc, delta, rs);
+            if (__any(valid && !(fabs(delta) < 1.0e-7))) phi2 = kappa * sin_tab(arg, p.trig);
+            const double rs_next = fma(rs, cd, rc * sd);
+            rc = fma(rc, cd, -(rs * sd));
+            rs = rs_next;
+          } else {
+            phi2 = valid ? p.rhs_values[e1 * n + k] * fscale : 0.0;
+          }
+          // a slice past the end contributes zeros: T_0 = 0 makes the whole recurrence vanish
+          const double seed = valid ? 1.0 : 0.0;
+          phi2 *= seed;
+          double Tm2 = seed, Tm1 = tk * seed;
+          const double tt = tk + tk;
+          rr[0] += phi2;
+          mom[1] += Tm1;
+          rr[1] = fma(Tm1, phi2, rr[1]);
+#pragma unroll
+          for (int d = 2; d <= kTop; ++d) {
+            const double Td = fma(tt, Tm1, -Tm2);
+            mom[d] += Td;
+            rr[d] = fma(Td, phi2, rr[d]);
+            Tm2 = Tm1;
+            Tm1 = Td;
+          }
+        }
       }
-      const int j1 = min(j0 + kReseedLarge, iters);
-      for (int j = j0; j < j1; ++j) {
-        const int k = s + 4 * j;
+      // the slices of an element add their partial sums into LDS (no shuffles, no registers)
+#pragma unroll
+      for (int d = 1; d <= kTop; ++d) lds_add(&mo[d], mom[d]);
+#pragma unroll
+      for (int d = 0; d <= kTop; ++d) lds_add(&ro[d], rr[d]);
+    }
+    {
+      double sq[15], nb[15];
+#pragma unroll
+      for (int j = 0; j < 15; ++j) sq[j] = nb[j] = 0.0;
+      for (int j = 0; j < iters; ++j) {
+        const int k = s + kSlices * j;
         const bool valid = k < n;
-        // np.linspace / mapdomain, two roundings each; last point = b
         const double xk = (k == n - 1) ? b : (double)k * step + a;
         const double tk = dm.off + dm.scl * xk;
-        double phi2;
-        if constexpr (RHS == LSSVR_RHS_SIN) {
-          const double arg = p.rhs_omega * xk;
-          const double delta = fma(-(double)(j - j0), dth4, arg - th0);
-          phi2 = fma(rc, delta, rs);
-          if (__any(valid && !(fabs(delta) < 1.0e-7))) phi2 = kappa * sin_tab(arg, p.trig);
-          const double rs_next = fma(rs, cd, rc * sd);
-          rc = fma(rc, cd, -(rs * sd));
-          rs = rs_next;
-        } else {
-          phi2 = valid ? p.rhs_values[e1 * n + k] * fscale : 0.0;
-        }
-        // a slice past the end contributes zeros: T_0 = 0 makes the whole recurrence vanish
         const double seed = valid ? 1.0 : 0.0;
-        phi2 *= seed;
         double Tm2 = seed, Tm1 = tk * seed;
         const double tt = tk + tk;
-        rr[0] += phi2;
-        mom[1] += Tm1;
-        rr[1] = fma(Tm1, phi2, rr[1]);
 #pragma unroll
         for (int d = 2; d <= kTop; ++d) {
           const double Td = fma(tt, Tm1, -Tm2);
-          mom[d] += Td;
-          rr[d] = fma(Td, phi2, rr[d]);
           if (d - 1 >= 15) nb[d - 1 - 15] = fma(Tm1, Td, nb[d - 1 - 15]);     // T_{d-1} T_d
           if (d >= 16) sq[d - 16] = fma(Td, Td, sq[d - 16]);                   // T_d^2
           Tm2 = Tm1;
           Tm1 = Td;
         }
       }
-    }
-    // combine the four slices of an element
+      // raw sums at the upper moments' places: m_{2j} <- sum T_j^2, m_{2j+1} <- sum T_j T_{j+1}
 #pragma unroll
-    for (int d = 1; d <= kTop; ++d) {
-      mom[d] += __shfl_xor(mom[d], 1);
-      mom[d] += __shfl_xor(mom[d], 2);
-    }
+      for (int j = 16; j <= 30; ++j) lds_add(&mo[2 * j], sq[j - 16]);
 #pragma unroll
-    for (int d = 0; d <= kTop; ++d) {
-      rr[d] += __shfl_xor(rr[d], 1);
-      rr[d] += __shfl_xor(rr[d], 2);
+      for (int j = 15; j <= 29; ++j) lds_add(&mo[2 * j + 1], nb[j - 15]);
     }
-#pragma unroll
-    for (int j = 0; j < 15; ++j) {
-      sq[j] += __shfl_xor(sq[j], 1);
-      sq[j] += __shfl_xor(sq[j], 2);
-      nb[j] += __shfl_xor(nb[j], 1);
-      nb[j] += __shfl_xor(nb[j], 2);
-    }
-    // all 61 moments -> LDS (each slice lane writes a quarter), m_{2j} = 2 sum T_j^2 - m_0,
-    // m_{2j+1} = 2 sum T_j T_{j+1} - m_1
-    double* const mo = Mom + i1 * kMomStride;
-    double* const ro = Rv + i1 * kRStride;
+    wave_lds_sync();
+    // m_0 = n;  m_{2j} = 2 sum T_j^2 - m_0,  m_{2j+1} = 2 sum T_j T_{j+1} - m_1  (slice lane d mod 4)
     const double m0 = (double)n;
-    if (s == 0) {
-      mo[0] = m0;
+    const double m1 = mo[1];
+    if (s == 0) mo[0] = m0;
 #pragma unroll
-      for (int d = 1; d <= 15; ++d) mo[d] = mom[d];
-#pragma unroll
-      for (int i = 0; i <= 7; ++i) ro[i] = rr[i];
-    } else if (s == 1) {
-#pragma unroll
-      for (int d = 16; d <= 30; ++d) mo[d] = mom[d];
-#pragma unroll
-      for (int i = 8; i <= 15; ++i) ro[i] = rr[i];
-    } else if (s == 2) {
-#pragma unroll
-      for (int j = 16; j <= 30; ++j) mo[2 * j] = fma(2.0, sq[j - 16], -m0);
-#pragma unroll
-      for (int i = 16; i <= 23; ++i) ro[i] = rr[i];
-    } else {
-#pragma unroll
-      for (int j = 15; j <= 29; ++j) mo[2 * j + 1] = fma(2.0, nb[j - 15], -mom[1]);
-#pragma unroll
-      for (int i = 24; i <= 30; ++i) ro[i] = rr[i];
-      mo[61] = mo[62] = mo[63] = 0.0;
-      ro[31] = 0.0;
-    }
+    for (int d = 31; d <= 60; ++d)
+      if ((d & (kSlices - 1)) == s) mo[d] = fma(2.0, mo[d], -((d & 1) ? m1 : m0));
   }
   wave_lds_sync();
 
-  // =========================== phase 2: solve, two elements per round ======================
-  const int c = lane & 31, h = lane >> 5;
-  double* const Eh = lds + kMomDoubles + kRDoubles + h * kHalfDoubles2;   // exact C rows (cold path)
-  double* const Fh = Eh + 64;                                             // C_z rows (cold path)
-  double* const Z = Fh + 64;                                              // 64 entries, [32, 64) stay 0
-  Z[32 + c] = 0.0;
-  const bool in_sys = c < MR;
-  const double alpha_c = in_sys ? kTab.alpha[c] : 0.0;
-  const double b_c = in_sys ? kTab.b[c] : 0.0;
-  const double slope_c = kTab.slope[c < 31 ? c : 30];
-  const bool c_even = (c & 1) == 0;
+  // =========================== phase 2: solve, four elements per round =====================
+  // lane (g = lane >> 4, q = lane & 15): element 4 round + g, columns q and q + 16 of its system
+  int q = lane & 15;
+  asm volatile("" : "+v"(q));      // (keeps phase 2's lane constants out of phase 1's register budget)
+  const int g = lane >> 4;
+  double* const Z = lds + kMomDoubles + kRDoubles + kNDoubles + g * kQuarterDoubles;
+  Z[32 + q] = 0.0;
+  Z[48 + q] = 0.0;
+  const int cA = q, cB = q + 16;
+  const bool inA = cA < MR, inB = cB < MR;
+  const double alA = inA ? kTab.alpha[cA] : 0.0, bA = inA ? kTab.b[cA] : 0.0;
+  const double alB = inB ? kTab.alpha[cB] : 0.0, bB = inB ? kTab.b[cB] : 0.0;
+  const double slA = kTab.slope[cA], slB = kTab.slope[cB < 31 ? cB : 30];
+  const bool q_even = (q & 1) == 0;                 // cA and cB have the parity of q
 
 #pragma unroll 1
-  for (int q = 0; q < kEPW / 2; ++q) {
-    const int loc = 2 * q + h;
+  for (int rd = 0; rd < kEPW / 4; ++rd) {
+    const int loc = 4 * rd + g;
+    if (E0 + 4 * rd >= p.ne) break;                      // (uniform: the whole round is past the end)
     const int64_t e_raw = E0 + loc;
-    if (E0 + 2 * q >= p.ne) break;                       // (uniform: both halves past the end)
     bool live = e_raw < p.ne;
     const int64_t e = live ? e_raw : p.ne - 1;
     int64_t id = e;
     if (p.elem_ids) {
       id = p.elem_ids[e];
       if (id < 0 || id >= p.ne_mesh) {     // out-of-range id: nothing of the mesh is touched
-        if (live && c == 0 && p.fail_count) atomicAdd(p.fail_count, 1);
+        if (live && q == 0 && p.fail_count) atomicAdd(p.fail_count, 1);
         live = false;
         id = 0;
       }
@@ -268,118 +300,164 @@ __global__ __launch_bounds__(64, 2) void enhance_large_cheb_kernel(EnhanceArgs p
     if (any_slow) idet = rcp_newton(tb - ta);
     const double d0 = (tb * gl - ta * gr) * idet;
     const double d1 = (gr - gl) * idet;
-    // this lane's own (C0_c, C1_c) of w_{0,1} = d - C v (v-basis)
-    double C0c, C1c;
-    if (c_even) {
-      C0c = fma(-slope_c, sig, 1.0);
-      C1c = slope_c * del;
+    // this lane's own (C0, C1) of w_{0,1} = d - C v for its two columns (v-basis)
+    double C0A, C1A, C0B, C1B;
+    if (q_even) {
+      C0A = fma(-slA, sig, 1.0);
+      C1A = slA * del;
+      C0B = fma(-slB, sig, 1.0);
+      C1B = slB * del;
     } else {
-      C0c = (slope_c - 1.0) * del;
-      C1c = fma(-(slope_c - 1.0), sig, 1.0);
+      C0A = (slA - 1.0) * del;
+      C1A = fma(-(slA - 1.0), sig, 1.0);
+      C0B = (slB - 1.0) * del;
+      C1B = fma(-(slB - 1.0), sig, 1.0);
     }
-    double C0z = 0.0, C1z = 0.0;                     // cold path: this lane's column of C_z = C Y
+    double C0zA = 0.0, C1zA = 0.0, C0zB = 0.0, C1zB = 0.0;    // cold path: columns of C_z = C Y
     if (any_slow) {
-      // exact L_{c+2}(ta), L_{c+2}(tb) by the Legendre recurrence, latch at degree c + 2
-      double am1 = 1.0, a0 = ta, bm1 = 1.0, b0 = tb, La2 = 0.0, Lb2 = 0.0;
+      // exact L_{c+2}(ta), L_{c+2}(tb) by the Legendre recurrence, latched at degrees cA+2, cB+2
+      double am1 = 1.0, a0 = ta, bm1 = 1.0, b0 = tb;
+      double LaA = 0.0, LbA = 0.0, LaB = 0.0, LbB = 0.0;
       for (int m = 1; m <= MR; ++m) {
         const double inv = 1.0 / (double)(m + 1);
         const double a1 = ((double)(2 * m + 1) * ta * a0 - (double)m * am1) * inv;
         const double b1 = ((double)(2 * m + 1) * tb * b0 - (double)m * bm1) * inv;
         am1 = a0; a0 = a1;
         bm1 = b0; b0 = b1;
-        if (m == c + 1) {
-          La2 = a1;
-          Lb2 = b1;
-        }
+        if (m == cA + 1) { LaA = a1; LbA = b1; }
+        if (m == cB + 1) { LaB = a1; LbB = b1; }
       }
-      C0c = (tb * La2 - ta * Lb2) * idet;
-      C1c = (Lb2 - La2) * idet;
-      if (!in_sys) C0c = C1c = 0.0;
-      wave_lds_sync();
-      Eh[2 * c] = C0c;
-      Eh[2 * c + 1] = C1c;
-      wave_lds_sync();
-      // C_z[., c] = sum_{j <= c, j = c mod 2} C[., j] Y[j][c]
+      C0A = (tb * LaA - ta * LbA) * idet;
+      C1A = (LbA - LaA) * idet;
+      C0B = (tb * LaB - ta * LbB) * idet;
+      C1B = (LbB - LaB) * idet;
+      if (!inA) C0A = C1A = 0.0;
+      if (!inB) C0B = C1B = 0.0;
+      // C_z[., c] = sum_{j <= c, j = c mod 2} C[., j] Y[j][c]; C[., j] lives in lane (j & 15) of
+      // this 16-lane row, first or second column (cold path: plain shuffles)
+      const int rowbase = lane & ~15;
       for (int t = 0; t < 16; ++t) {
-        const int j = c - 2 * t;
-        if (j >= 0 && in_sys) {
-          const double y = kTab.Y[j][c];
-          C0z = fma(Eh[2 * j], y, C0z);
-          C1z = fma(Eh[2 * j + 1], y, C1z);
+        const int jA = cA - 2 * t, jB = cB - 2 * t;
+        const int sA = rowbase + ((jA >= 0 ? jA : 0) & 15), sB = rowbase + ((jB >= 0 ? jB : 0) & 15);
+        const double a0A = __shfl(C0A, sA), a1A = __shfl(C1A, sA);       // jA < 16 always
+        const double b0lo = __shfl(C0A, sB), b1lo = __shfl(C1A, sB);
+        const double b0hi = __shfl(C0B, sB), b1hi = __shfl(C1B, sB);
+        if (jA >= 0 && inA) {
+          const double y = kTab.Y[jA][cA];
+          C0zA = fma(a0A, y, C0zA);
+          C1zA = fma(a1A, y, C1zA);
+        }
+        if (jB >= 0 && inB) {
+          const double y = kTab.Y[jB][cB];
+          C0zB = fma(jB < 16 ? b0lo : b0hi, y, C0zB);
+          C1zB = fma(jB < 16 ? b1lo : b1hi, y, C1zB);
         }
       }
-      Fh[2 * c] = C0z;
-      Fh[2 * c + 1] = C1z;
-      wave_lds_sync();
     }
-    if (!in_sys) C0c = C1c = 0.0;
+    if (!inA) C0A = C1A = 0.0;
+    if (!inB) C0B = C1B = 0.0;
 
-    // ---- right-hand side entry of this lane's column, then column c of S2 -------------------------
+    // ---- right-hand side entries of this lane's columns, then the two columns of S2 --------------
     const double* const mo = Mom + loc * kMomStride;
     const double* const ro = Rv + loc * kRStride;
-    double rhs_c;
+    double rhsA, rhsB;
     if (any_slow) {
-      rhs_c = fma(eps2, fma(C0z, d0, C1z * d1), ro[c]);
+      rhsA = fma(eps2, fma(C0zA, d0, C1zA * d1), ro[cA]);
+      rhsB = fma(eps2, fma(C0zB, d0, C1zB * d1), ro[cB]);
     } else {
-      const double e_d = eps2 * (c_even ? d0 : d1);
-      const double q_c = eps2 * (c_even ? fma(del, d1, -(sig * d0)) : fma(del, d0, -(sig * d1)));
-      rhs_c = fma(b_c, q_c, fma(alpha_c, e_d, ro[c]));
+      const double e_d = eps2 * (q_even ? d0 : d1);
+      const double q_c = eps2 * (q_even ? fma(del, d1, -(sig * d0)) : fma(del, d0, -(sig * d1)));
+      rhsA = fma(bA, q_c, fma(alA, e_d, ro[cA]));
+      rhsB = fma(bB, q_c, fma(alB, e_d, ro[cB]));
     }
-    if (!in_sys) rhs_c = 0.0;
+    if (!inA) rhsA = 0.0;
+    if (!inB) rhsB = 0.0;
     wave_lds_sync();                 // previous round's readers of Z are done
-    Z[c] = rhs_c;
+    Z[cA] = rhsA;
+    Z[cB] = rhsB;
     wave_lds_sync();
-    double col[kLP];
+    double A[kLP], B[kLP];
     {
       const double es = eps2 * sig, ed = eps2 * del;
       // coefficients of alpha_i / b_i in the first-order ridge, by the parity of the ROW
-      const double u1 = fma(eps2, alpha_c, -(es * b_c)), u2 = -(es * alpha_c);   // same parity
-      const double u3 = ed * b_c, u4 = ed * alpha_c;                             // opposite parity
-      const double Xe = c_even ? u1 : u3, Ye = c_even ? u2 : u4;                 // even rows
-      const double Xo = c_even ? u3 : u1, Yo = c_even ? u4 : u2;                 // odd rows
-      const int cc = c < 31 ? c : 0;
+      const double u1A = fma(eps2, alA, -(es * bA)), u2A = -(es * alA), u3A = ed * bA, u4A = ed * alA;
+      const double u1B = fma(eps2, alB, -(es * bB)), u2B = -(es * alB), u3B = ed * bB, u4B = ed * alB;
+      const double XeA = q_even ? u1A : u3A, YeA = q_even ? u2A : u4A;     // even rows
+      const double XoA = q_even ? u3A : u1A, YoA = q_even ? u4A : u2A;     // odd rows
+      const double XeB = q_even ? u1B : u3B, YeB = q_even ? u2B : u4B;
+      const double XoB = q_even ? u3B : u1B, YoB = q_even ? u4B : u2B;
+      const int cBc = cB < 31 ? cB : 0;                    // (lane 15's second column is the rhs)
+      // the 62 table entries N[i][c] first, straight into the column registers: all loads in
+      // flight at once (interleaved with their uses they were issued one at a time -- the wave
+      // spent half its life in s_waitcnt)
 #pragma unroll
       for (int i = 0; i < kLP - 1; ++i) {
-        const int lo_idx = (i >= cc) ? i - cc : cc - i;
-        double v = mo[i + cc] + mo[lo_idx];
-        const double nic = kTab.N[i][cc];
-        if (any_slow) {
-          v = fma(eps2, fma(Fh[2 * i], C0z, fma(Fh[2 * i + 1], C1z, nic)), v);
-        } else {
-          v = fma(eps2, nic, v);
-          v = fma(cheb::kAlpha[i], (i & 1) ? Xo : Xe, v);
-          v = fma(cheb::kB[i], (i & 1) ? Yo : Ye, v);
-        }
-        // lane 31 carries the right-hand side as a column; padding columns are inert
-        col[i] = (c == kRhsRow) ? Z[i] : (in_sys ? v : 0.0);
+        A[i] = kTab.N[i][cA];
+        B[i] = kTab.N[i][cBc];
       }
-      col[kRhsRow] = rhs_c;          // ... and every column carries it as row 31
+#pragma unroll
+      for (int i = 0; i < kLP - 1; ++i) {
+        double vA = mo[i + cA] + mo[(i >= cA) ? i - cA : cA - i];
+        double vB = mo[i + cBc] + mo[(i >= cBc) ? i - cBc : cBc - i];
+        if (any_slow) {
+          // C_z[., i]: lane (i & 15) of the row, first / second column
+          const int si = (lane & ~15) + (i & 15);
+          const double f0 = __shfl(i < 16 ? C0zA : C0zB, si), f1 = __shfl(i < 16 ? C1zA : C1zB, si);
+          vA = fma(eps2, fma(f0, C0zA, fma(f1, C1zA, A[i])), vA);
+          vB = fma(eps2, fma(f0, C0zB, fma(f1, C1zB, B[i])), vB);
+        } else {
+          vA = fma(eps2, A[i], vA);
+          vA = fma(cheb::kAlpha[i], (i & 1) ? XoA : XeA, vA);
+          vA = fma(cheb::kB[i], (i & 1) ? YoA : YeA, vA);
+          vB = fma(eps2, B[i], vB);
+          vB = fma(cheb::kAlpha[i], (i & 1) ? XoB : XeB, vB);
+          vB = fma(cheb::kB[i], (i & 1) ? YoB : YeB, vB);
+        }
+        A[i] = inA ? vA : 0.0;
+        // column 31 carries the right-hand side as a column; padding columns are inert
+        B[i] = (cB == kRhsRow) ? Z[i] : (inB ? vB : 0.0);
+      }
+      A[kRhsRow] = rhsA;             // ... and every column carries it as row 31
+      B[kRhsRow] = rhsB;
     }
 
-    // ---- LDL^T factor + solve of the MR x MR block ------------------------------------------
+    // ---- LDL^T factor + solve of the MR x MR block, four systems in lock step -----------------
     bool lane_ok;
-    const double z = ldlt_solve_dpp(col, Z, c, MR, lane_ok);
+    double zA, zB;
+    ldlt_solve_dpp4(A, B, q, MR, lane_ok, zA, zB);
     // v = Y z (bubble Legendre coefficients): v_j = sum_{i >= j, i = j mod 2} Y[j][i] z_i
     wave_lds_sync();
-    Z[c] = in_sys ? z : 0.0;
+    Z[cA] = inA ? zA : 0.0;
+    Z[cB] = inB ? zB : 0.0;
     wave_lds_sync();
-    double v = 0.0;
+    double vA = 0.0, vB = 0.0;
     {
-      const int jr = c < 31 ? c : 30;
+      const int jB = cB < 31 ? cB : 30;
+      double yA[16], yB[16];             // (all 32 table loads in flight before the first use)
 #pragma unroll
-      for (int t = 0; t < 16; ++t) v = fma(kTab.Y[jr][c + 2 * t], Z[c + 2 * t], v);
-      if (!in_sys) v = 0.0;
+      for (int t = 0; t < 16; ++t) {
+        yA[t] = kTab.Y[cA][cA + 2 * t];
+        yB[t] = kTab.Y[jB][cB + 2 * t];
+      }
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        vA = fma(yA[t], Z[cA + 2 * t], vA);
+        vB = fma(yB[t], Z[cB + 2 * t], vB);
+      }
+      if (!inA) vA = 0.0;
+      if (!inB) vB = 0.0;
     }
-    const double w0 = d0 - half_sum(C0c * v);
-    const double w1 = d1 - half_sum(C1c * v);
-    const double bad = half_sum((lane_ok && fabs(v) < 1.0e300) ? 0.0 : 1.0);
+    const double w0 = d0 - row_sum16(fma(C0A, vA, C0B * vB));
+    const double w1 = d1 - row_sum16(fma(C1A, vA, C1B * vB));
+    const double bad = row_sum16((lane_ok && fabs(vA) < 1.0e300 && fabs(vB) < 1.0e300) ? 0.0 : 1.0);
     const bool ok = (bad == 0.0) && (fabs(w0) < 1e300) && (fabs(w1) < 1e300);
 
-    // ---- store: lane c -> W[e][c+2]; lane 0 also writes w0, w1 -----------------------------
+    // ---- store: lane q -> W[e][q+2], W[e][q+18]; lane 0 also writes w0, w1 -------------------
     if (live) {
       double* const Wrow = p.W + id * (p.ldw ? p.ldw : (int64_t)M);
-      if (in_sys) Wrow[c + 2] = ok ? v : 0.0;
-      if (c == 0) {
+      if (inA) Wrow[cA + 2] = ok ? vA : 0.0;
+      if (inB) Wrow[cB + 2] = ok ? vB : 0.0;
+      if (q == 0) {
         Wrow[0] = ok ? w0 : 0.5 * (gl + gr);
         Wrow[1] = ok ? w1 : 0.5 * (gr - gl);
         if (p.status) p.status[id] = ok ? LSSVR_ST_OK : LSSVR_ST_FALLBACK;

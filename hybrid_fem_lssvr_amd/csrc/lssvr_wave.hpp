@@ -243,5 +243,90 @@ __device__ __forceinline__ double ldlt_solve_dpp(double (&col)[kLP], double* __r
   return (c < nsys) ? Y * rinv : 0.0;
 }
 
+
+// ---------------------------------------------------------------------------
+// FOUR systems per wave: 16 lanes per system, TWO columns per lane (lane q of a 16-lane DPP row
+// holds columns q and q + 16 of its system, rows in registers: A[i], B[i]).  The pivot row of
+// step j, seen across the columns, is the register pair (A[j], B[j]) of the row's 16 lanes, so
+//     a_ic -= a_ji t_c     is     v_fmac_f64_dpp  X[i], (i < 16 ? A[j] : B[j]), nt_X  row_newbcast:(i & 15)
+// with no cross-row movement at all (ldlt_solve_dpp needs two v_permlane16_swap pairs per step
+// because its systems span two DPP rows).  Per step the bookkeeping (pivot reciprocal, the two
+// multipliers, the freeze masks) is shared by four systems instead of two, and once j >= 16 the
+// first column of every lane is frozen, so only the second one is updated: 872 broadcast-FMAs
+// and ~12 bookkeeping instructions per step for four systems, against 527 + 17 for two.
+// The right-hand side rides along as row 31 of every column (forward substitution for free);
+// the back-substitution broadcasts z_i the same way (no LDS).
+// On exit zA / zB = solution components of columns q / q + 16 (0 beyond nsys).
+//
+// HAZARD (gfx950): a DPP operand read of a VGPR needs two wait states after a VALU write of that
+// VGPR, and hipcc cannot see the DPP inside an asm statement.  Every DPP source here (tA, tB, the
+// reciprocal, the scaled solution) is therefore passed through an `s_nop 1` statement right
+// after it is produced and is not written again before its last DPP read.  Nothing but the
+// register allocator could put a VALU write in between (a live-range split copy); that is checked
+// on the ISA of every build by scripts/check_dpp_hazard.py (run from __graft_entry__.build()), and
+// the parity tests tests/test_gpu_enhance_large.py (all M = 15..33) exercise the result.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void ldlt_solve_dpp4(double (&A)[kLP], double (&B)[kLP], int q, int nsys,
+                                                bool& lane_ok, double& zA, double& zB) {
+  int qq = q;
+  asm volatile("" : "+v"(qq));     // opaque copies: keep the lane masks / uniform conditions
+  int ns = nsys;                   // from being hoisted out of the caller's round loop
+  asm volatile("" : "+s"(ns));
+  double nrA = -1.0, nrB = -1.0;   // -1/d of this lane's own pivots, latched at their steps
+  static_for<0, kLP - 1>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    if (j < ns) {
+      double tA = A[j], tB = B[j];                          // row j across the columns
+      double nr = -rcp_newton(j < 16 ? tA : tB);            // lane (j & 15): -1/d_j
+      if constexpr (j < 16) {
+        if (qq == j) nrA = nr;
+      } else {
+        if (qq == j - 16) nrB = nr;
+      }
+      asm volatile("s_nop 1" : "+v"(tA), "+v"(tB), "+v"(nr));
+      double ntA = 0.0, ntB = 0.0;                          // -a_jc / d_j of the two columns
+      if constexpr (j < 16) {
+        fmac_rowbcast<(j & 15)>(ntA, nr, tA);
+        if (!(qq > j)) ntA = 0.0;                           // frozen columns stay as they are
+        fmac_rowbcast<(j & 15)>(ntB, nr, tB);
+      } else {
+        fmac_rowbcast<(j & 15)>(ntB, nr, tB);
+        if (!(qq > j - 16)) ntB = 0.0;
+      }
+      asm volatile("s_nop 0" : "+v"(ntA), "+v"(ntB));
+      static_for<j + 1, kLP>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if constexpr (j < 16) fmac_rowbcast<(i & 15)>(A[i], i < 16 ? tA : tB, ntA);
+        fmac_rowbcast<(i & 15)>(B[i], i < 16 ? tA : tB, ntB);
+      });
+    }
+  });
+  const int cA = q, cB = q + 16;
+  lane_ok = ((nrA < 0.0) || (cA >= nsys)) && ((nrB < 0.0) || (cB >= nsys));
+  // backward substitution L^T z = D^-1 y out of the frozen columns: column t keeps
+  // Y_t = y_t - sum_{i>t} a_it z_i; the owner of column i publishes -z_i = Y_i (-1/d_i) by DPP
+  double YA = A[kRhsRow], YB = B[kRhsRow];
+  if (cA >= nsys) { YA = 0.0; nrA = 0.0; }
+  if (cB >= nsys) { YB = 0.0; nrB = 0.0; }
+  asm volatile("" : "+s"(ns));
+  static_for<1, kLP - 1>([&](auto ir) {
+    constexpr int i = kLP - 1 - decltype(ir)::value;        // i = 30 .. 1
+    if (i < ns) {
+      double nz = (i < 16) ? YA * nrA : YB * nrB;           // lane (i & 15): -z_i
+      asm volatile("s_nop 1" : "+v"(nz));
+      if constexpr (i < 16) {
+        const double mA = (qq < i) ? A[i] : 0.0;            // a_it, t = column q < i
+        fmac_rowbcast<(i & 15)>(YA, nz, mA);
+      } else {
+        fmac_rowbcast<(i & 15)>(YA, nz, A[i]);              // every first column is < i
+        const double mB = (qq < i - 16) ? B[i] : 0.0;
+        fmac_rowbcast<(i & 15)>(YB, nz, mB);
+      }
+    }
+  });
+  zA = -(YA * nrA);
+  zB = -(YB * nrB);
+}
+
 }  // namespace wave
 }  // namespace lssvr

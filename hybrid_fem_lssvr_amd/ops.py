@@ -12,7 +12,8 @@ import math
 import torch
 
 from . import _capi
-from ._capi import RHS_ARRAY, RHS_SIN, SOLVER_DUAL, SOLVER_PRIMAL, SOLVER_PRIMAL_WAVE  # noqa: F401
+from ._capi import (RHS_ARRAY, RHS_SIN, SOLVER_DUAL, SOLVER_PRIMAL, SOLVER_PRIMAL_MOMENT,  # noqa: F401
+                    SOLVER_PRIMAL_WAVE)
 
 SOLVER_SHARED = 100      # facade-level choice for UNIFORM meshes: routed to lssvr_enhance_shared
 

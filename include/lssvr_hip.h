@@ -57,6 +57,10 @@ extern "C" {
                                  pivoting, two steps of iterative refinement.  n_colloc <= 64,
                                  M <= 33, Poisson and variable-coefficient rows.  <= 1e-12 of
                                  the exact minimiser on every BASELINE config  */
+#define LSSVR_SOLVER_PRIMAL_MOMENT 3 /* same algorithm as PRIMAL in the two-phase wave mapping of
+                                 csrc/enhance_large_cheb.hip (Chebyshev-moment Gram, four systems
+                                 per wave in the LDL^T); any M, Poisson rows; for A/B measurements:
+                                 half the instructions of PRIMAL_WAVE, 10-20 % slower */
 #define LSSVR_SOLVER_PRIMAL_WAVE 2 /* same algorithm as PRIMAL, forced onto the
                                  wave-per-element / f64-MFMA Gram mapping whatever M is
                                  (PRIMAL picks lane-per-element for M <= 22); for A/B

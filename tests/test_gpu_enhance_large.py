@@ -128,3 +128,32 @@ def test_fallback_status_large(dev):
     assert int(cnt.item()) == 3
     assert np.allclose(W[10, :2], [0.5 * (values[10] + values[11]), 0.5 * (values[11] - values[10])])
     assert np.all(W[10, 2:] == 0)
+
+
+@pytest.mark.parametrize("M,n,ne", [(33, 64, 24), (33, 64, 1003), (25, 48, 77), (9, 16, 130), (16, 31, 35), (4, 7, 19)])
+def test_moment_wave_mapping_vs_default(dev, M, n, ne):
+    """LSSVR_SOLVER_PRIMAL_MOMENT (csrc/enhance_large_cheb.hip: Chebyshev-moment Gram, sixteen elements
+    per wave, four systems per wave in the DPP LDL^T) against the oracle and the default kernels:
+    every tail of the 16-element blocks and of the 4-element rounds, any M."""
+    from hybrid_fem_lssvr_amd import ops
+    rng = np.random.default_rng(900 + M + ne)
+    nodes = np.cumsum(np.concatenate([[-0.7], rng.uniform(0.01, 0.08, ne)]))
+    values = np.sin(np.pi * nodes) + 0.01 * rng.standard_normal(ne + 1)
+    gd = (nodes[0], nodes[-1])
+    W, st = _enhance(dev, nodes, values, M, 1e4, n, global_domain=gd, solver=ops.SOLVER_PRIMAL_MOMENT)
+    assert np.all(st == 0)
+    Wo = orc.enhance_all_vec(nodes, values, M, 1e4, n, global_domain=gd)
+    assert orc.rel_l2_coef(W, Wo).max() <= 1e-11
+    Wd, _ = _enhance(dev, nodes, values, M, 1e4, n, global_domain=gd)
+    assert orc.rel_l2_coef(W, Wd).max() <= 1e-11
+    if cf.HAVE_MP:
+        sel = [0, ne // 2, ne - 1]
+        tr = cf.truth_all(nodes, values, M, 1e4, n, orc.poisson_rhs, gd, sel)
+        assert orc.rel_l2_coef(W[sel], tr).max() <= TOL_TRUTH
+    # tabulated rhs == in-kernel sin
+    import torch
+    x = _t(nodes, dev)
+    f = _t(orc.poisson_rhs(ops.colloc_points(x, n).cpu().numpy()), dev)
+    W2, _ = ops.enhance(x, _t(values, dev), M, 1e4, n, global_domain=gd, rhs_values=f, solver=ops.SOLVER_PRIMAL_MOMENT)
+    torch.cuda.synchronize()
+    assert orc.rel_l2_coef(W2.cpu().numpy(), W).max() <= 1e-12
