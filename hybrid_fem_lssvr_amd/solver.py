@@ -327,8 +327,11 @@ class FEMLSSVRPrimalSolver:
             # exact-structure solution of A = D^T K D by the element-flux prefix scan
             u = ops.p1_flux_solve(bands["kloc"], bands["load"], u0, u1)
         else:
-            # the float64 matrix scikit-fem would assemble (rounded diagonal included), as
-            # `enforce` + `solve` see it (Dual.py:129-130)
+            # the ASSEMBLED float64 bands (rounded diagonal included) through `enforce` + `solve`
+            # semantics (Dual.py:129-130).  Which matrix scikit-fem itself assembles is an
+            # assumption of SURVEY.md Appendix C -- parity unpinned, the package is not importable
+            # here (the reference negates both forms, Dual.py:117-124: -K u = -b; this code
+            # assembles +K u = +b, the same u)
             u = ops.tridiag_dirichlet_solve(bands["diag"], bands["off"], bands["load"], u0, u1)
         self.bands = bands
         self._x_dev, self._u_dev = x, u
