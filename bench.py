@@ -761,10 +761,11 @@ def run_single(args, D, M, n, ne_glob, lo, hi, dev, cpu_res, use_dist):
                 "gfx950 are the same 78.6 TFLOP/s and share one pipe (DESIGN.md section 3)")
         solver_lbl = "primal, BC-eliminated SPD (M-2), Chebyshev-moment Gram, LDL^T"
     else:
-        kernel_name, bound = "enhance_large_kernel", "mfma"
-        pipe = ("FP64: f64 MFMA (4x4x4 blocks) Gram + DPP-broadcast LDL^T; FP64 vector and matrix share one pipe "
-                "at the same 78.6 TFLOP/s peak (DESIGN.md section 3)")
-        solver_lbl = "primal, BC-eliminated SPD (M-2), LDL^T"
+        kernel_name, bound = "moments_kernel + solve4_kernel (the pair, gap included)", "fp64-valu"
+        pipe = ("FP64 vector pipe: Chebyshev moments (lane per element) + four-systems-per-wave DPP-broadcast LDL^T; "
+                "the f64-MFMA Gram kernel (LSSVR_SOLVER_PRIMAL_WAVE) is 1.4-1.5x slower (DESIGN.md section 3.8); "
+                "vector and matrix FP64 share one pipe at the same 78.6 TFLOP/s peak")
+        solver_lbl = "primal, BC-eliminated SPD (M-2), Chebyshev-moment Gram, LDL^T (two kernels, workspace)"
     out = {
         "metric": "LSSVR-enhanced elements/sec, 1D Poisson deg-%d/%d-pt" % (args.degree, n),
         "value": total / elapsed,

@@ -16,7 +16,7 @@ IN_TREE_LIB = os.path.join(_HERE, "csrc", "liblssvr_hip.so")
 # test suite and the benchmark always exercise the one in-tree library.
 LIB_PATH = os.environ.get("LSSVR_HIP_LIB") or IN_TREE_LIB
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 RHS_ARRAY = 0
 RHS_SIN = 1
@@ -41,6 +41,12 @@ SIGNATURES = {
                                _c_int, _c_int, _c_dbl,
                                _c_int, C.POINTER(_c_dbl), _c_dp, _c_int,
                                _c_dp, _c_dp, _c_dp, _c_dp]),
+    "lssvr_enhance_work_bytes": (_c_i64, [_c_i64, _c_int, _c_int, _c_int]),
+    "lssvr_enhance_ws": (_c_int, [_c_dp, _c_dp, _c_i64, _c_i64, _c_i64,
+                                  _c_dbl, _c_dbl, _c_dbl, _c_dbl,
+                                  _c_int, _c_int, _c_dbl,
+                                  _c_int, C.POINTER(_c_dbl), _c_dp, _c_int,
+                                  _c_dp, _c_dp, _c_dp, _c_dp, _c_i64, _c_dp, C.POINTER(C.c_float)]),
     "lssvr_enhance_profiled": (_c_int, [_c_dp, _c_dp, _c_i64, _c_i64, _c_i64,
                                         _c_dbl, _c_dbl, _c_dbl, _c_dbl,
                                         _c_int, _c_int, _c_dbl,

@@ -83,7 +83,7 @@ int set_rhs(lssvr::EnhanceArgs& a, int rhs_id, const double* rhs_params_host,
 namespace {
 // shared tail of lssvr_enhance / lssvr_enhance_profiled
 int enhance_dispatch(const lssvr::EnhanceArgs& a, int solver_id, hipStream_t s,
-                     const lssvr::LaunchOpts* o) {
+                     const lssvr::LaunchOpts* o, void* work = nullptr, int64_t work_bytes = 0) {
   // Fewer collocation points than bubble coefficients: the primal normal equations are rank
   // deficient (float64 returns O(1) errors there), the dual Gram system is well conditioned.
   if (solver_id != LSSVR_SOLVER_DUAL && a.n < a.M - 2) solver_id = LSSVR_SOLVER_DUAL;
@@ -96,11 +96,17 @@ int enhance_dispatch(const lssvr::EnhanceArgs& a, int solver_id, hipStream_t s,
     return check_launch(lssvr::enhance_small(a, s, o), "enhance_small");
   if (a.elem_ids && solver_id != LSSVR_SOLVER_PRIMAL)
     return fail(LSSVR_ERR_SOLVER, "subset launches take LSSVR_SOLVER_PRIMAL");
-  // large degree: the direct Gram on the f64 matrix cores; the Chebyshev-moment wave kernel (half
-  // the instructions, but 2 resident waves per SIMD instead of 3: 10-20 % slower, DESIGN.md
-  // section 9) only on request
+  // large degree, Poisson rows, workspace given: Chebyshev moments + four-systems-per-wave solve as
+  // two kernels (1.4-1.5x the speed of the MFMA kernel)
+  if (solver_id == LSSVR_SOLVER_PRIMAL && !a.a_values && !a.elem_ids && work &&
+      work_bytes >= lssvr::enhance_moment_ws_bytes(a.ne))
+    return check_launch(lssvr::enhance_large_split(a, work, s, o), "enhance_large_split");
+  // otherwise the direct Gram on the f64 matrix cores; LSSVR_SOLVER_PRIMAL_MOMENT forces the moment
+  // form (fused single kernel without a workspace: 2 resident waves per SIMD, slower)
   if (solver_id == LSSVR_SOLVER_PRIMAL_MOMENT) {
     if (a.a_values) return fail(LSSVR_ERR_SOLVER, "LSSVR_SOLVER_PRIMAL_MOMENT: Poisson rows only");
+    if (work && work_bytes >= lssvr::enhance_moment_ws_bytes(a.ne) && !a.elem_ids)
+      return check_launch(lssvr::enhance_large_split(a, work, s, o), "enhance_large_split");
     return check_launch(lssvr::enhance_large_cheb(a, s, o), "enhance_large_cheb");
   }
   return check_launch(lssvr::enhance_large(a, s, o), "enhance_large");
@@ -131,6 +137,48 @@ int lssvr_enhance(const double* x, const double* u, int64_t ne, int64_t elem_off
     return fail(LSSVR_ERR_SOLVER, "unknown solver_id %d", solver_id);
   if (ne == 0) return LSSVR_OK;
   return enhance_dispatch(a, solver_id, reinterpret_cast<hipStream_t>(stream), nullptr);
+}
+
+int64_t lssvr_enhance_work_bytes(int64_t ne, int M, int n_colloc, int solver_id) {
+  (void)n_colloc;
+  if (ne <= 0 || M <= lssvr::kSmallMaxM) return 0;
+  if (solver_id != LSSVR_SOLVER_PRIMAL && solver_id != LSSVR_SOLVER_PRIMAL_MOMENT) return 0;
+  return lssvr::enhance_moment_ws_bytes(ne);
+}
+
+int lssvr_enhance_ws(const double* x, const double* u, int64_t ne, int64_t elem_offset,
+                     int64_t ne_global, double gxmin, double gxmax, double bc_left, double bc_right,
+                     int M, int n_colloc, double gamma, int rhs_id, const double* rhs_params_host,
+                     const double* rhs_values, int solver_id, double* W, int32_t* status,
+                     int32_t* fail_count, void* work, int64_t work_bytes, void* stream,
+                     float* kernel_ms_host) {
+  lssvr::EnhanceArgs a;
+  int rc = fill_enhance_args(a, x, u, ne, elem_offset, ne_global, gxmin, gxmax, bc_left, bc_right,
+                             M, n_colloc, gamma, W);
+  if (rc != LSSVR_OK) return rc;
+  rc = set_rhs(a, rhs_id, rhs_params_host, rhs_values, ne > 0, "ne");
+  if (rc != LSSVR_OK) return rc;
+  a.status = status;
+  a.fail_count = fail_count;
+  if (solver_id != LSSVR_SOLVER_PRIMAL && solver_id != LSSVR_SOLVER_DUAL &&
+      solver_id != LSSVR_SOLVER_PRIMAL_WAVE && solver_id != LSSVR_SOLVER_PRIMAL_MOMENT)
+    return fail(LSSVR_ERR_SOLVER, "unknown solver_id %d", solver_id);
+  if (work_bytes < 0 || (work_bytes > 0 && !work)) return fail(LSSVR_ERR_NULL, "work / work_bytes inconsistent");
+  if (ne == 0) return LSSVR_OK;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (!kernel_ms_host) return enhance_dispatch(a, solver_id, s, nullptr, work, work_bytes);
+  lssvr::LaunchOpts o;
+  if (hipEventCreate(&o.start) != hipSuccess || hipEventCreate(&o.stop) != hipSuccess)
+    return fail(LSSVR_ERR_LAUNCH, "hipEventCreate failed");
+  rc = enhance_dispatch(a, solver_id, s, &o, work, work_bytes);
+  if (rc == LSSVR_OK) {
+    hipError_t e = hipEventSynchronize(o.stop);
+    if (e == hipSuccess) e = hipEventElapsedTime(kernel_ms_host, o.start, o.stop);
+    if (e != hipSuccess) rc = fail(LSSVR_ERR_LAUNCH, "profiled launch: %s", hipGetErrorString(e));
+  }
+  (void)hipEventDestroy(o.start);
+  (void)hipEventDestroy(o.stop);
+  return rc;
 }
 
 int lssvr_enhance_profiled(const double* x, const double* u, int64_t ne, int64_t elem_offset,

@@ -99,6 +99,241 @@ __device__ const ChebDeviceTables kTab = make_cheb_device_tables();
 
 }  // namespace
 
+
+// ---------------------------------------------------------------------------------------------
+// One round of phase 2: four elements (one per 16-lane DPP row), from their moments mo[0..60] and
+// right-hand sides ro[0..30] (LDS, this lane's element) to the stored coefficient row.  Lane
+// (g = lane >> 4, q = lane & 15) owns columns q and q + 16 of its element's system.
+// Z: this row's 64 doubles of LDS ([32, 64) stay zero).
+// ---------------------------------------------------------------------------------------------
+// Ntab (row stride 32) / Ytab (row stride 64): the device tables or LDS copies of them.
+// PRE: the element's a, b, g_l, g_r come with the moments (mo[61..63], ro[31]; split kernels).
+template <bool PRE>
+__device__ __forceinline__ void solve_four(const EnhanceArgs& p, const int lane, const int64_t e_raw,
+                                           const double* __restrict__ mo,
+                                           const double* __restrict__ ro, double* __restrict__ Z,
+                                           const double* __restrict__ Ntab,
+                                           const double* __restrict__ Ytab) {
+  const int M = p.M, MR = M - 2;
+  int q = lane & 15;
+  asm volatile("" : "+v"(q));      // (keeps phase 2's lane constants out of phase 1's register budget)
+  Z[32 + q] = 0.0;
+  Z[48 + q] = 0.0;
+  const int cA = q, cB = q + 16;
+  const bool inA = cA < MR, inB = cB < MR;
+  const double alA = inA ? kTab.alpha[cA] : 0.0, bA = inA ? kTab.b[cA] : 0.0;
+  const double alB = inB ? kTab.alpha[cB] : 0.0, bB = inB ? kTab.b[cB] : 0.0;
+  const double slA = kTab.slope[cA], slB = kTab.slope[cB < 31 ? cB : 30];
+  const bool q_even = (q & 1) == 0;                 // cA and cB have the parity of q
+
+  {
+    bool live = e_raw < p.ne;
+    const int64_t e = live ? e_raw : p.ne - 1;
+    int64_t id = e;
+    if (p.elem_ids) {
+      id = p.elem_ids[e];
+      if (id < 0 || id >= p.ne_mesh) {     // out-of-range id: nothing of the mesh is touched
+        if (live && q == 0 && p.fail_count) atomicAdd(p.fail_count, 1);
+        live = false;
+        id = 0;
+      }
+    }
+    double a, b, gl, gr;
+    if constexpr (PRE) {
+      a = mo[61];
+      b = mo[62];
+      gl = mo[63];
+      gr = ro[31];
+    } else {
+      a = p.x[id];
+      b = p.x[id + 1];
+      const int64_t eg = id + p.elem_offset;
+      gl = (eg == 0 && a == p.gxmin) ? p.bc_left : p.u[id];
+      gr = (eg == p.ne_global - 1 && b == p.gxmax) ? p.bc_right : p.u[id + 1];
+    }
+    const double inv_gamma = p.gamma_values ? rcp_newton(p.gamma_values[id]) : p.inv_gamma;
+    const DomainMap dm = map_params(a, b);
+    const double hh = 0.5 * dm.oldlen;
+    const double inv_scl2 = hh * hh;
+    const double eps2 = (2.0 * inv_gamma) * (inv_scl2 * inv_scl2);
+
+    // ---- boundary rows to first order (enhance_small_cheb.hpp); exact recurrence when the wave
+    // holds an element beyond the first-order range
+    const double ta = dm.off + dm.scl * a;
+    const double tb = dm.off + dm.scl * b;
+    const double ea = 1.0 + ta, eb = 1.0 - tb;
+    const double sig = 0.5 * (ea + eb), del = 0.5 * (ea - eb);
+    const double amax = 0.5 * (double)((M - 1) * M);
+    const bool slow = amax * fmax(fabs(ea), fabs(eb)) >= 1.0e-6;
+    const bool any_slow = __any(slow);
+    double idet = 0.5 * fma(sig, 1.0 + sig, 1.0);
+    if (any_slow) idet = rcp_newton(tb - ta);
+    const double d0 = (tb * gl - ta * gr) * idet;
+    const double d1 = (gr - gl) * idet;
+    // this lane's own (C0, C1) of w_{0,1} = d - C v for its two columns (v-basis)
+    double C0A, C1A, C0B, C1B;
+    if (q_even) {
+      C0A = fma(-slA, sig, 1.0);
+      C1A = slA * del;
+      C0B = fma(-slB, sig, 1.0);
+      C1B = slB * del;
+    } else {
+      C0A = (slA - 1.0) * del;
+      C1A = fma(-(slA - 1.0), sig, 1.0);
+      C0B = (slB - 1.0) * del;
+      C1B = fma(-(slB - 1.0), sig, 1.0);
+    }
+    double C0zA = 0.0, C1zA = 0.0, C0zB = 0.0, C1zB = 0.0;    // cold path: columns of C_z = C Y
+    if (any_slow) {
+      // exact L_{c+2}(ta), L_{c+2}(tb) by the Legendre recurrence, latched at degrees cA+2, cB+2
+      double am1 = 1.0, a0 = ta, bm1 = 1.0, b0 = tb;
+      double LaA = 0.0, LbA = 0.0, LaB = 0.0, LbB = 0.0;
+      for (int m = 1; m <= MR; ++m) {
+        const double inv = 1.0 / (double)(m + 1);
+        const double a1 = ((double)(2 * m + 1) * ta * a0 - (double)m * am1) * inv;
+        const double b1 = ((double)(2 * m + 1) * tb * b0 - (double)m * bm1) * inv;
+        am1 = a0; a0 = a1;
+        bm1 = b0; b0 = b1;
+        if (m == cA + 1) { LaA = a1; LbA = b1; }
+        if (m == cB + 1) { LaB = a1; LbB = b1; }
+      }
+      C0A = (tb * LaA - ta * LbA) * idet;
+      C1A = (LbA - LaA) * idet;
+      C0B = (tb * LaB - ta * LbB) * idet;
+      C1B = (LbB - LaB) * idet;
+      if (!inA) C0A = C1A = 0.0;
+      if (!inB) C0B = C1B = 0.0;
+      // C_z[., c] = sum_{j <= c, j = c mod 2} C[., j] Y[j][c]; C[., j] lives in lane (j & 15) of
+      // this 16-lane row, first or second column (cold path: plain shuffles)
+      const int rowbase = lane & ~15;
+      for (int t = 0; t < 16; ++t) {
+        const int jA = cA - 2 * t, jB = cB - 2 * t;
+        const int sA = rowbase + ((jA >= 0 ? jA : 0) & 15), sB = rowbase + ((jB >= 0 ? jB : 0) & 15);
+        const double a0A = __shfl(C0A, sA), a1A = __shfl(C1A, sA);       // jA < 16 always
+        const double b0lo = __shfl(C0A, sB), b1lo = __shfl(C1A, sB);
+        const double b0hi = __shfl(C0B, sB), b1hi = __shfl(C1B, sB);
+        if (jA >= 0 && inA) {
+          const double y = Ytab[jA * 64 + cA];
+          C0zA = fma(a0A, y, C0zA);
+          C1zA = fma(a1A, y, C1zA);
+        }
+        if (jB >= 0 && inB) {
+          const double y = Ytab[jB * 64 + cB];
+          C0zB = fma(jB < 16 ? b0lo : b0hi, y, C0zB);
+          C1zB = fma(jB < 16 ? b1lo : b1hi, y, C1zB);
+        }
+      }
+    }
+    if (!inA) C0A = C1A = 0.0;
+    if (!inB) C0B = C1B = 0.0;
+
+    // ---- right-hand side entries of this lane's columns, then the two columns of S2 --------------
+    double rhsA, rhsB;
+    if (any_slow) {
+      rhsA = fma(eps2, fma(C0zA, d0, C1zA * d1), ro[cA]);
+      rhsB = fma(eps2, fma(C0zB, d0, C1zB * d1), ro[cB]);
+    } else {
+      const double e_d = eps2 * (q_even ? d0 : d1);
+      const double q_c = eps2 * (q_even ? fma(del, d1, -(sig * d0)) : fma(del, d0, -(sig * d1)));
+      rhsA = fma(bA, q_c, fma(alA, e_d, ro[cA]));
+      rhsB = fma(bB, q_c, fma(alB, e_d, ro[cB]));
+    }
+    if (!inA) rhsA = 0.0;
+    if (!inB) rhsB = 0.0;
+    wave_lds_sync();                 // previous round's readers of Z are done
+    Z[cA] = rhsA;
+    Z[cB] = rhsB;
+    wave_lds_sync();
+    double A[kLP], B[kLP];
+    {
+      const double es = eps2 * sig, ed = eps2 * del;
+      const int cBc = cB < 31 ? cB : 0;                    // (lane 15's second column is the rhs)
+      // the 62 table entries N[i][c] first, straight into the column registers: all loads in
+      // flight at once
+#pragma unroll
+      for (int i = 0; i < kLP - 1; ++i) {
+        A[i] = Ntab[i * 32 + cA];
+        B[i] = Ntab[i * 32 + cBc];
+      }
+      // one column at a time (half the coefficient registers live): first-order ridge
+      //   same parity:  eps2 (N_ic + al_i al_c) - es (al_i b_c + b_i al_c),   opposite:  ed (al_i b_c + b_i al_c)
+      auto column = [&](double (&X)[kLP], const int cx, const double alc, const double bc,
+                        const double C0z, const double C1z, const bool inx) {
+        const double u1 = fma(eps2, alc, -(es * bc)), u2 = -(es * alc), u3 = ed * bc, u4 = ed * alc;
+        const double Xe = q_even ? u1 : u3, Ye = q_even ? u2 : u4;       // even rows
+        const double Xo = q_even ? u3 : u1, Yo = q_even ? u4 : u2;       // odd rows
+#pragma unroll
+        for (int i = 0; i < kLP - 1; ++i) {
+          double v = mo[i + cx] + mo[(i >= cx) ? i - cx : cx - i];
+          if (any_slow) {
+            // C_z[., i]: lane (i & 15) of the row, first / second column
+            const int si = (lane & ~15) + (i & 15);
+            const double f0 = __shfl(i < 16 ? C0zA : C0zB, si), f1 = __shfl(i < 16 ? C1zA : C1zB, si);
+            v = fma(eps2, fma(f0, C0z, fma(f1, C1z, X[i])), v);
+          } else {
+            v = fma(eps2, X[i], v);
+            v = fma(cheb::kAlpha[i], (i & 1) ? Xo : Xe, v);
+            v = fma(cheb::kB[i], (i & 1) ? Yo : Ye, v);
+          }
+          X[i] = inx ? v : 0.0;
+        }
+      };
+      column(A, cA, alA, bA, C0zA, C1zA, inA);
+      column(B, cBc, alB, bB, C0zB, C1zB, inB);
+      if (cB == kRhsRow) {           // column 31 carries the right-hand side as a column
+#pragma unroll
+        for (int i = 0; i < kLP - 1; ++i) B[i] = Z[i];
+      }
+      A[kRhsRow] = rhsA;             // ... and every column carries it as row 31
+      B[kRhsRow] = rhsB;
+    }
+
+    // ---- LDL^T factor + solve of the MR x MR block, four systems in lock step -----------------
+    bool lane_ok;
+    double zA, zB;
+    ldlt_solve_dpp4(A, B, q, MR, lane_ok, zA, zB);
+    // v = Y z (bubble Legendre coefficients): v_j = sum_{i >= j, i = j mod 2} Y[j][i] z_i
+    wave_lds_sync();
+    Z[cA] = inA ? zA : 0.0;
+    Z[cB] = inB ? zB : 0.0;
+    wave_lds_sync();
+    double vA = 0.0, vB = 0.0;
+    {
+      const int jB = cB < 31 ? cB : 30;
+      double yA[16], yB[16];             // (all 32 table loads in flight before the first use)
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        yA[t] = Ytab[cA * 64 + cA + 2 * t];
+        yB[t] = Ytab[jB * 64 + cB + 2 * t];
+      }
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        vA = fma(yA[t], Z[cA + 2 * t], vA);
+        vB = fma(yB[t], Z[cB + 2 * t], vB);
+      }
+      if (!inA) vA = 0.0;
+      if (!inB) vB = 0.0;
+    }
+    const double w0 = d0 - row_sum16(fma(C0A, vA, C0B * vB));
+    const double w1 = d1 - row_sum16(fma(C1A, vA, C1B * vB));
+    const double bad = row_sum16((lane_ok && fabs(vA) < 1.0e300 && fabs(vB) < 1.0e300) ? 0.0 : 1.0);
+    const bool ok = (bad == 0.0) && (fabs(w0) < 1e300) && (fabs(w1) < 1e300);
+
+    // ---- store: lane q -> W[e][q+2], W[e][q+18]; lane 0 also writes w0, w1 -------------------
+    if (live) {
+      double* const Wrow = p.W + id * (p.ldw ? p.ldw : (int64_t)M);
+      if (inA) Wrow[cA + 2] = ok ? vA : 0.0;
+      if (inB) Wrow[cB + 2] = ok ? vB : 0.0;
+      if (q == 0) {
+        Wrow[0] = ok ? w0 : 0.5 * (gl + gr);
+        Wrow[1] = ok ? w1 : 0.5 * (gr - gl);
+        if (p.status) p.status[id] = ok ? LSSVR_ST_OK : LSSVR_ST_FALLBACK;
+        if (!ok && p.fail_count) atomicAdd(p.fail_count, 1);
+      }
+    }
+  }
+}
+
 template <int RHS>
 __global__ __launch_bounds__(64, 2) void enhance_large_cheb_kernel(EnhanceArgs p, unsigned nxcd) {
   __shared__ double2_t lds2[kLdsDoubles / 2];
@@ -106,7 +341,7 @@ __global__ __launch_bounds__(64, 2) void enhance_large_cheb_kernel(EnhanceArgs p
   double* const Mom = lds;
   double* const Rv = lds + kMomDoubles;
   const int lane = threadIdx.x & 63;
-  const int M = p.M, MR = M - 2, n = p.n;
+  const int n = p.n;
 
   // XCD-aware numbering: consecutive 16-element blocks go to consecutive workgroups OF ONE XCD, so
   // the lines of x / u are fetched by one L2 (enhance_large.hip measured 2.5 MB instead of 7.2 MB)
@@ -246,225 +481,158 @@ __global__ __launch_bounds__(64, 2) void enhance_large_cheb_kernel(EnhanceArgs p
   wave_lds_sync();
 
   // =========================== phase 2: solve, four elements per round =====================
-  // lane (g = lane >> 4, q = lane & 15): element 4 round + g, columns q and q + 16 of its system
-  int q = lane & 15;
-  asm volatile("" : "+v"(q));      // (keeps phase 2's lane constants out of phase 1's register budget)
-  const int g = lane >> 4;
-  double* const Z = lds + kMomDoubles + kRDoubles + kNDoubles + g * kQuarterDoubles;
-  Z[32 + q] = 0.0;
-  Z[48 + q] = 0.0;
-  const int cA = q, cB = q + 16;
-  const bool inA = cA < MR, inB = cB < MR;
-  const double alA = inA ? kTab.alpha[cA] : 0.0, bA = inA ? kTab.b[cA] : 0.0;
-  const double alB = inB ? kTab.alpha[cB] : 0.0, bB = inB ? kTab.b[cB] : 0.0;
-  const double slA = kTab.slope[cA], slB = kTab.slope[cB < 31 ? cB : 30];
-  const bool q_even = (q & 1) == 0;                 // cA and cB have the parity of q
-
+  {
+    const int g = lane >> 4;
+    double* const Z = lds + kMomDoubles + kRDoubles + kNDoubles + g * kQuarterDoubles;
 #pragma unroll 1
-  for (int rd = 0; rd < kEPW / 4; ++rd) {
-    const int loc = 4 * rd + g;
-    if (E0 + 4 * rd >= p.ne) break;                      // (uniform: the whole round is past the end)
-    const int64_t e_raw = E0 + loc;
-    bool live = e_raw < p.ne;
-    const int64_t e = live ? e_raw : p.ne - 1;
-    int64_t id = e;
-    if (p.elem_ids) {
-      id = p.elem_ids[e];
-      if (id < 0 || id >= p.ne_mesh) {     // out-of-range id: nothing of the mesh is touched
-        if (live && q == 0 && p.fail_count) atomicAdd(p.fail_count, 1);
-        live = false;
-        id = 0;
-      }
+    for (int rd = 0; rd < kEPW / 4; ++rd) {
+      const int loc = 4 * rd + g;
+      if (E0 + 4 * rd >= p.ne) break;                    // (uniform: the whole round is past the end)
+      solve_four<false>(p, lane, E0 + loc, Mom + loc * kMomStride, Rv + loc * kRStride, Z,
+                        &kTab.N[0][0], &kTab.Y[0][0]);
     }
-    const double a = p.x[id];
-    const double b = p.x[id + 1];
-    const int64_t eg = id + p.elem_offset;
-    const double gl = (eg == 0 && a == p.gxmin) ? p.bc_left : p.u[id];
-    const double gr = (eg == p.ne_global - 1 && b == p.gxmax) ? p.bc_right : p.u[id + 1];
-    const double inv_gamma = p.gamma_values ? rcp_newton(p.gamma_values[id]) : p.inv_gamma;
-    const DomainMap dm = map_params(a, b);
-    const double hh = 0.5 * dm.oldlen;
-    const double inv_scl2 = hh * hh;
-    const double eps2 = (2.0 * inv_gamma) * (inv_scl2 * inv_scl2);
+  }
+}
 
-    // ---- boundary rows to first order (enhance_small_cheb.hpp); exact recurrence when the wave
-    // holds an element beyond the first-order range
-    const double ta = dm.off + dm.scl * a;
-    const double tb = dm.off + dm.scl * b;
-    const double ea = 1.0 + ta, eb = 1.0 - tb;
-    const double sig = 0.5 * (ea + eb), del = 0.5 * (ea - eb);
-    const double amax = 0.5 * (double)((M - 1) * M);
-    const bool slow = amax * fmax(fabs(ea), fabs(eb)) >= 1.0e-6;
-    const bool any_slow = __any(slow);
-    double idet = 0.5 * fma(sig, 1.0 + sig, 1.0);
-    if (any_slow) idet = rcp_newton(tb - ta);
-    const double d0 = (tb * gl - ta * gr) * idet;
-    const double d1 = (gr - gl) * idet;
-    // this lane's own (C0, C1) of w_{0,1} = d - C v for its two columns (v-basis)
-    double C0A, C1A, C0B, C1B;
-    if (q_even) {
-      C0A = fma(-slA, sig, 1.0);
-      C1A = slA * del;
-      C0B = fma(-slB, sig, 1.0);
-      C1B = slB * del;
-    } else {
-      C0A = (slA - 1.0) * del;
-      C1A = fma(-(slA - 1.0), sig, 1.0);
-      C0B = (slB - 1.0) * del;
-      C1B = fma(-(slB - 1.0), sig, 1.0);
-    }
-    double C0zA = 0.0, C1zA = 0.0, C0zB = 0.0, C1zB = 0.0;    // cold path: columns of C_z = C Y
-    if (any_slow) {
-      // exact L_{c+2}(ta), L_{c+2}(tb) by the Legendre recurrence, latched at degrees cA+2, cB+2
-      double am1 = 1.0, a0 = ta, bm1 = 1.0, b0 = tb;
-      double LaA = 0.0, LbA = 0.0, LaB = 0.0, LbB = 0.0;
-      for (int m = 1; m <= MR; ++m) {
-        const double inv = 1.0 / (double)(m + 1);
-        const double a1 = ((double)(2 * m + 1) * ta * a0 - (double)m * am1) * inv;
-        const double b1 = ((double)(2 * m + 1) * tb * b0 - (double)m * bm1) * inv;
-        am1 = a0; a0 = a1;
-        bm1 = b0; b0 = b1;
-        if (m == cA + 1) { LaA = a1; LbA = b1; }
-        if (m == cB + 1) { LaB = a1; LbB = b1; }
-      }
-      C0A = (tb * LaA - ta * LbA) * idet;
-      C1A = (LbA - LaA) * idet;
-      C0B = (tb * LaB - ta * LbB) * idet;
-      C1B = (LbB - LaB) * idet;
-      if (!inA) C0A = C1A = 0.0;
-      if (!inB) C0B = C1B = 0.0;
-      // C_z[., c] = sum_{j <= c, j = c mod 2} C[., j] Y[j][c]; C[., j] lives in lane (j & 15) of
-      // this 16-lane row, first or second column (cold path: plain shuffles)
-      const int rowbase = lane & ~15;
-      for (int t = 0; t < 16; ++t) {
-        const int jA = cA - 2 * t, jB = cB - 2 * t;
-        const int sA = rowbase + ((jA >= 0 ? jA : 0) & 15), sB = rowbase + ((jB >= 0 ? jB : 0) & 15);
-        const double a0A = __shfl(C0A, sA), a1A = __shfl(C1A, sA);       // jA < 16 always
-        const double b0lo = __shfl(C0A, sB), b1lo = __shfl(C1A, sB);
-        const double b0hi = __shfl(C0B, sB), b1hi = __shfl(C1B, sB);
-        if (jA >= 0 && inA) {
-          const double y = kTab.Y[jA][cA];
-          C0zA = fma(a0A, y, C0zA);
-          C1zA = fma(a1A, y, C1zA);
-        }
-        if (jB >= 0 && inB) {
-          const double y = kTab.Y[jB][cB];
-          C0zB = fma(jB < 16 ? b0lo : b0hi, y, C0zB);
-          C1zB = fma(jB < 16 ? b1lo : b1hi, y, C1zB);
-        }
-      }
-    }
-    if (!inA) C0A = C1A = 0.0;
-    if (!inB) C0B = C1B = 0.0;
 
-    // ---- right-hand side entries of this lane's columns, then the two columns of S2 --------------
-    const double* const mo = Mom + loc * kMomStride;
-    const double* const ro = Rv + loc * kRStride;
-    double rhsA, rhsB;
-    if (any_slow) {
-      rhsA = fma(eps2, fma(C0zA, d0, C1zA * d1), ro[cA]);
-      rhsB = fma(eps2, fma(C0zB, d0, C1zB * d1), ro[cB]);
-    } else {
-      const double e_d = eps2 * (q_even ? d0 : d1);
-      const double q_c = eps2 * (q_even ? fma(del, d1, -(sig * d0)) : fma(del, d0, -(sig * d1)));
-      rhsA = fma(bA, q_c, fma(alA, e_d, ro[cA]));
-      rhsB = fma(bB, q_c, fma(alB, e_d, ro[cB]));
-    }
-    if (!inA) rhsA = 0.0;
-    if (!inB) rhsB = 0.0;
-    wave_lds_sync();                 // previous round's readers of Z are done
-    Z[cA] = rhsA;
-    Z[cB] = rhsB;
-    wave_lds_sync();
-    double A[kLP], B[kLP];
-    {
-      const double es = eps2 * sig, ed = eps2 * del;
-      // coefficients of alpha_i / b_i in the first-order ridge, by the parity of the ROW
-      const double u1A = fma(eps2, alA, -(es * bA)), u2A = -(es * alA), u3A = ed * bA, u4A = ed * alA;
-      const double u1B = fma(eps2, alB, -(es * bB)), u2B = -(es * alB), u3B = ed * bB, u4B = ed * alB;
-      const double XeA = q_even ? u1A : u3A, YeA = q_even ? u2A : u4A;     // even rows
-      const double XoA = q_even ? u3A : u1A, YoA = q_even ? u4A : u2A;     // odd rows
-      const double XeB = q_even ? u1B : u3B, YeB = q_even ? u2B : u4B;
-      const double XoB = q_even ? u3B : u1B, YoB = q_even ? u4B : u2B;
-      const int cBc = cB < 31 ? cB : 0;                    // (lane 15's second column is the rhs)
-      // the 62 table entries N[i][c] first, straight into the column registers: all loads in
-      // flight at once (interleaved with their uses they were issued one at a time -- the wave
-      // spent half its life in s_waitcnt)
-#pragma unroll
-      for (int i = 0; i < kLP - 1; ++i) {
-        A[i] = kTab.N[i][cA];
-        B[i] = kTab.N[i][cBc];
-      }
-#pragma unroll
-      for (int i = 0; i < kLP - 1; ++i) {
-        double vA = mo[i + cA] + mo[(i >= cA) ? i - cA : cA - i];
-        double vB = mo[i + cBc] + mo[(i >= cBc) ? i - cBc : cBc - i];
-        if (any_slow) {
-          // C_z[., i]: lane (i & 15) of the row, first / second column
-          const int si = (lane & ~15) + (i & 15);
-          const double f0 = __shfl(i < 16 ? C0zA : C0zB, si), f1 = __shfl(i < 16 ? C1zA : C1zB, si);
-          vA = fma(eps2, fma(f0, C0zA, fma(f1, C1zA, A[i])), vA);
-          vB = fma(eps2, fma(f0, C0zB, fma(f1, C1zB, B[i])), vB);
-        } else {
-          vA = fma(eps2, A[i], vA);
-          vA = fma(cheb::kAlpha[i], (i & 1) ? XoA : XeA, vA);
-          vA = fma(cheb::kB[i], (i & 1) ? YoA : YeA, vA);
-          vB = fma(eps2, B[i], vB);
-          vB = fma(cheb::kAlpha[i], (i & 1) ? XoB : XeB, vB);
-          vB = fma(cheb::kB[i], (i & 1) ? YoB : YeB, vB);
-        }
-        A[i] = inA ? vA : 0.0;
-        // column 31 carries the right-hand side as a column; padding columns are inert
-        B[i] = (cB == kRhsRow) ? Z[i] : (inB ? vB : 0.0);
-      }
-      A[kRhsRow] = rhsA;             // ... and every column carries it as row 31
-      B[kRhsRow] = rhsB;
-    }
+// =============================================================================================
+// The same two phases as TWO kernels with a caller-provided workspace in between (96 doubles per
+// element: lssvr_enhance_work_bytes): the solve kernel then holds nothing but the two columns per
+// lane and fits the register budget of three resident waves per SIMD, its waves are short (four
+// elements each) and the tables sit in LDS -- what the fused kernel above lacks.
+// This pair is the DEFAULT for Poisson rows above M = 22 whenever the caller passes a workspace
+// (lssvr_enhance_ws): 263 us at 1e5 elements and 2.3 ms at 1e6 (M = 33, 64 points) against
+// 352-395 us and 3.2 ms of enhance_large_kernel.
+// =============================================================================================
+constexpr int kWsStride = 96;            // per element: m_0..m_60 at [0, 61), r_0..r_30 at [64, 95)
 
-    // ---- LDL^T factor + solve of the MR x MR block, four systems in lock step -----------------
-    bool lane_ok;
-    double zA, zB;
-    ldlt_solve_dpp4(A, B, q, MR, lane_ok, zA, zB);
-    // v = Y z (bubble Legendre coefficients): v_j = sum_{i >= j, i = j mod 2} Y[j][i] z_i
-    wave_lds_sync();
-    Z[cA] = inA ? zA : 0.0;
-    Z[cB] = inB ? zB : 0.0;
-    wave_lds_sync();
-    double vA = 0.0, vB = 0.0;
-    {
-      const int jB = cB < 31 ? cB : 30;
-      double yA[16], yB[16];             // (all 32 table loads in flight before the first use)
+// Phase 1 alone, ONE ELEMENT PER LANE (no slices, no reduction): 91 accumulators, all points.
+template <int RHS>
+__global__ __launch_bounds__(256, 2) void moments_kernel(EnhanceArgs p, double* __restrict__ ws) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = e < p.ne;
+  const int64_t ec = live ? e : p.ne - 1;
+  int64_t id = ec;
+  if (p.elem_ids) {
+    id = p.elem_ids[ec];
+    if (id < 0 || id >= p.ne_mesh) id = 0;
+  }
+  const int n = p.n;
+  const double a = p.x[id];
+  const double b = p.x[id + 1];
+  const DomainMap dm = map_params(a, b);
+  const double step = dm.oldlen / (double)(n - 1);
+  const double hh = 0.5 * dm.oldlen;
+  const double inv_scl2 = hh * hh;
+  double mom[kTop + 1], sq[15], nb[15], rr[kTop + 1];
 #pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        yA[t] = kTab.Y[cA][cA + 2 * t];
-        yB[t] = kTab.Y[jB][cB + 2 * t];
-      }
+  for (int d = 0; d <= kTop; ++d) mom[d] = rr[d] = 0.0;
 #pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        vA = fma(yA[t], Z[cA + 2 * t], vA);
-        vB = fma(yB[t], Z[cB + 2 * t], vB);
-      }
-      if (!inA) vA = 0.0;
-      if (!inB) vB = 0.0;
+  for (int j = 0; j < 15; ++j) sq[j] = nb[j] = 0.0;
+  double rs = 0.0, rc = 1.0, sd = 0.0, cd = 1.0, th0 = 0.0, dth = 0.0, kappa = 0.0;
+  if constexpr (RHS == LSSVR_RHS_SIN) {
+    dth = p.rhs_omega * step;
+    sincos_tab(dth, sd, cd, p.trig);
+    kappa = -2.0 * (p.rhs_amp * inv_scl2);
+  }
+  [[maybe_unused]] const double fscale = -2.0 * inv_scl2;
+  for (int k0 = 0; k0 < n; k0 += kReseedLarge) {
+    if constexpr (RHS == LSSVR_RHS_SIN) {
+      const double x0 = (k0 == 0) ? a : fma((double)k0, step, a);
+      th0 = p.rhs_omega * x0;
+      sincos_tab(th0, rs, rc, p.trig);
+      rs *= kappa;
+      rc *= kappa;
     }
-    const double w0 = d0 - row_sum16(fma(C0A, vA, C0B * vB));
-    const double w1 = d1 - row_sum16(fma(C1A, vA, C1B * vB));
-    const double bad = row_sum16((lane_ok && fabs(vA) < 1.0e300 && fabs(vB) < 1.0e300) ? 0.0 : 1.0);
-    const bool ok = (bad == 0.0) && (fabs(w0) < 1e300) && (fabs(w1) < 1e300);
-
-    // ---- store: lane q -> W[e][q+2], W[e][q+18]; lane 0 also writes w0, w1 -------------------
-    if (live) {
-      double* const Wrow = p.W + id * (p.ldw ? p.ldw : (int64_t)M);
-      if (inA) Wrow[cA + 2] = ok ? vA : 0.0;
-      if (inB) Wrow[cB + 2] = ok ? vB : 0.0;
-      if (q == 0) {
-        Wrow[0] = ok ? w0 : 0.5 * (gl + gr);
-        Wrow[1] = ok ? w1 : 0.5 * (gr - gl);
-        if (p.status) p.status[id] = ok ? LSSVR_ST_OK : LSSVR_ST_FALLBACK;
-        if (!ok && p.fail_count) atomicAdd(p.fail_count, 1);
+    const int k1 = min(k0 + kReseedLarge, n);
+    for (int k = k0; k < k1; ++k) {
+      const double xk = (k == n - 1) ? b : (double)k * step + a;
+      const double tk = dm.off + dm.scl * xk;
+      double phi2;
+      if constexpr (RHS == LSSVR_RHS_SIN) {
+        const double arg = p.rhs_omega * xk;
+        const double delta = fma(-(double)(k - k0), dth, arg - th0);
+        phi2 = fma(rc, delta, rs);
+        if (__any(!(fabs(delta) < 1.0e-7))) phi2 = kappa * sin_tab(arg, p.trig);
+        const double rs_next = fma(rs, cd, rc * sd);
+        rc = fma(rc, cd, -(rs * sd));
+        rs = rs_next;
+      } else {
+        phi2 = p.rhs_values[ec * n + k] * fscale;
+      }
+      double Tm2 = 1.0, Tm1 = tk;
+      const double tt = tk + tk;
+      rr[0] += phi2;
+      mom[1] += Tm1;
+      rr[1] = fma(Tm1, phi2, rr[1]);
+#pragma unroll
+      for (int d = 2; d <= kTop; ++d) {
+        const double Td = fma(tt, Tm1, -Tm2);
+        mom[d] += Td;
+        rr[d] = fma(Td, phi2, rr[d]);
+        if (d - 1 >= 15) nb[d - 1 - 15] = fma(Tm1, Td, nb[d - 1 - 15]);
+        if (d >= 16) sq[d - 16] = fma(Td, Td, sq[d - 16]);
+        Tm2 = Tm1;
+        Tm1 = Td;
       }
     }
   }
+  if (!live) return;
+  double* const o = ws + e * kWsStride;
+  const double m0 = (double)n;
+  o[0] = m0;
+#pragma unroll
+  for (int d = 1; d <= kTop; ++d) o[d] = mom[d];
+#pragma unroll
+  for (int j = 16; j <= 30; ++j) o[2 * j] = fma(2.0, sq[j - 16], -m0);
+#pragma unroll
+  for (int j = 15; j <= 29; ++j) o[2 * j + 1] = fma(2.0, nb[j - 15], -mom[1]);
+  // the element's end points and boundary values travel with the moments (Dual.py:65-75 rule)
+  const int64_t eg = id + p.elem_offset;
+  o[61] = a;
+  o[62] = b;
+  o[63] = (eg == 0 && a == p.gxmin) ? p.bc_left : p.u[id];
+#pragma unroll
+  for (int i = 0; i <= kTop; ++i) o[64 + i] = rr[i];
+  o[95] = (eg == p.ne_global - 1 && b == p.gxmax) ? p.bc_right : p.u[id + 1];
+}
+
+// Phase 2 alone: a workgroup of four waves = sixteen elements (four per wave); the moments come
+// from the workspace through LDS, the tables N and Y are copied to LDS once per workgroup (read
+// from the device tables they cost every wave ~60 exposed L1/L2 round trips: 58 % of its life in
+// s_waitcnt).
+constexpr int kS4Stride = 112;           // LDS per element: 96 + 16 (groups of a half on disjoint banks)
+constexpr int kS4Waves = 4;
+constexpr int kS4WaveDoubles = 4 * kS4Stride + 4 * 64;
+__global__ __launch_bounds__(64 * kS4Waves, 3) void solve4_kernel(EnhanceArgs p,
+                                                                   const double* __restrict__ ws,
+                                                                   unsigned nxcd) {
+  __shared__ double2_t lds2[(32 * 32 + 32 * 64 + kS4Waves * kS4WaveDoubles) / 2];
+  double* const Nl = reinterpret_cast<double*>(lds2);
+  double* const Yl = Nl + 32 * 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double* const lds = Yl + 32 * 64 + wave * kS4WaveDoubles;
+#pragma unroll
+  for (int t = 0; t < (32 * 32) / (64 * kS4Waves); ++t)
+    Nl[t * 64 * kS4Waves + tid] = (&kTab.N[0][0])[t * 64 * kS4Waves + tid];
+#pragma unroll
+  for (int t = 0; t < (32 * 64) / (64 * kS4Waves); ++t)
+    Yl[t * 64 * kS4Waves + tid] = (&kTab.Y[0][0])[t * 64 * kS4Waves + tid];
+  const unsigned xcd = blockIdx.x % nxcd, slot = blockIdx.x / nxcd;
+  const int64_t blk = (int64_t)xcd * (gridDim.x / nxcd) + slot;
+  const int64_t E0 = (blk * kS4Waves + wave) * 4;
+  const int64_t Ec = E0 < p.ne ? E0 : p.ne - 1;       // (a wave past the end works on duplicates, stores masked)
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const int idx = k * 64 + lane;                  // 384 = 4 x 96 doubles
+    const int el = idx / kWsStride, j = idx % kWsStride;
+    const int64_t e = (Ec + el < p.ne) ? Ec + el : p.ne - 1;
+    lds[el * kS4Stride + j] = ws[e * kWsStride + j];
+  }
+  __syncthreads();
+  const int g = lane >> 4;
+  double* const Z = lds + 4 * kS4Stride + g * 64;
+  solve_four<true>(p, lane, E0 + g, lds + g * kS4Stride, lds + g * kS4Stride + 64, Z, Nl, Yl);
 }
 
 hipError_t enhance_large_cheb(const EnhanceArgs& a, hipStream_t s, const LaunchOpts* o) {
@@ -477,6 +645,33 @@ hipError_t enhance_large_cheb(const EnhanceArgs& a, hipStream_t s, const LaunchO
   if (a.rhs_id == LSSVR_RHS_SIN)
     return launch(enhance_large_cheb_kernel<LSSVR_RHS_SIN>, grid, block, s, o, a, nxcd);
   return launch(enhance_large_cheb_kernel<LSSVR_RHS_ARRAY>, grid, block, s, o, a, nxcd);
+}
+
+int64_t enhance_moment_ws_bytes(int64_t ne) { return ne * kWsStride * (int64_t)sizeof(double); }
+
+hipError_t enhance_large_split(const EnhanceArgs& a, void* work, hipStream_t s, const LaunchOpts* o) {
+  if (a.M - 2 + 1 > kLP || a.a_values || !work) return hipErrorInvalidValue;
+  double* const ws = static_cast<double*>(work);
+  const unsigned nxcd = xcd_count();
+  const unsigned b1 = (unsigned)((a.ne + 255) / 256);
+  int64_t blocks = (a.ne + 4 * kS4Waves - 1) / (4 * kS4Waves);
+  blocks = (blocks + nxcd - 1) / nxcd * nxcd;
+  if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+  // profiled launches: the start stamp of the first kernel and the stop stamp of the second --
+  // the duration reported is that of the PAIR, gap included
+  const bool prof = o && o->start && o->stop;
+  if (a.rhs_id == LSSVR_RHS_SIN) {
+    if (prof) hipExtLaunchKernelGGL(moments_kernel<LSSVR_RHS_SIN>, dim3(b1), dim3(256), 0, s, o->start, nullptr, 0, a, ws);
+    else hipLaunchKernelGGL(moments_kernel<LSSVR_RHS_SIN>, dim3(b1), dim3(256), 0, s, a, ws);
+  } else {
+    if (prof) hipExtLaunchKernelGGL(moments_kernel<LSSVR_RHS_ARRAY>, dim3(b1), dim3(256), 0, s, o->start, nullptr, 0, a, ws);
+    else hipLaunchKernelGGL(moments_kernel<LSSVR_RHS_ARRAY>, dim3(b1), dim3(256), 0, s, a, ws);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  if (prof) hipExtLaunchKernelGGL(solve4_kernel, dim3((unsigned)blocks), dim3(64 * kS4Waves), 0, s, nullptr, o->stop, 0, a, (const double*)ws, nxcd);
+  else hipLaunchKernelGGL(solve4_kernel, dim3((unsigned)blocks), dim3(64 * kS4Waves), 0, s, a, (const double*)ws, nxcd);
+  return hipGetLastError();
 }
 
 }  // namespace lssvr

@@ -76,14 +76,34 @@ def _stream(stream):
     return int(stream)
 
 
+_WORK = {}
+
+
+def workspace(lib, device, ne, M, n_colloc, solver):
+    """Device scratch for ``lssvr_enhance_ws`` (``lssvr_enhance_work_bytes``): one buffer per device,
+    grown on demand, reused by every call on that device (calls on different streams of one device
+    that need it concurrently must pass their own ``work=`` tensor).  None when none is needed."""
+    nbytes = int(lib.lssvr_enhance_work_bytes(int(ne), int(M), int(n_colloc), int(solver)))
+    if nbytes <= 0:
+        return None
+    key = (device.type, device.index)
+    buf = _WORK.get(key)
+    if buf is None or buf.numel() * 8 < nbytes:
+        buf = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=device)
+        _WORK[key] = buf
+    return buf
+
+
 def enhance(x, u, M, gamma, n_colloc=12, *, rhs=(POISSON_AMP, POISSON_OMEGA), rhs_values=None,
             elem_offset=0, ne_global=None, global_domain=None, bc=(0.0, 0.0),
-            solver=SOLVER_PRIMAL, out=None, status=None, fail_count=None, stream=None):
+            solver=SOLVER_PRIMAL, out=None, status=None, fail_count=None, stream=None, work=None):
     """``solve_lssvr_subproblems`` (Dual.py:139-169) for the shard (x, u).
 
     x, u: float64[ne+1] device tensors.  Returns (W float64[ne, M], status int32[ne]).
     ``rhs`` = (amp, omega) evaluates f = amp*sin(omega*x) in-kernel; ``rhs_values``
     float64[ne, n_colloc] (f tabulated at ``colloc_points``) overrides it.
+    ``work``: device scratch for the two-kernel path above M = 22 (default: the per-device buffer
+    of :func:`workspace`; ``work=False`` runs the workspace-free kernels).
     """
     lib = _capi.load()
     _dev(x, "x")
@@ -107,12 +127,19 @@ def enhance(x, u, M, gamma, n_colloc=12, *, rhs=(POISSON_AMP, POISSON_OMEGA), rh
         rhs_id, params = RHS_ARRAY, None
     else:
         rhs_id, params = RHS_SIN, _capi.rhs_params(*rhs)
-    rc = lib.lssvr_enhance(_ptr(x), _ptr(u), ne, int(elem_offset), int(ne_global),
-                           float(global_domain[0]), float(global_domain[1]),
-                           float(bc[0]), float(bc[1]), int(M), int(n_colloc), float(gamma),
-                           rhs_id, params, _ptr(rhs_values), int(solver),
-                           _ptr(out), _ptr(status), _ptr(fail_count), _stream(stream))
-    _capi.check(rc, "lssvr_enhance")
+    if work is None:
+        work = workspace(lib, x.device, ne, M, n_colloc, solver)
+    elif work is False:
+        work = None
+    else:
+        _dev(work, "work")
+    rc = lib.lssvr_enhance_ws(_ptr(x), _ptr(u), ne, int(elem_offset), int(ne_global),
+                              float(global_domain[0]), float(global_domain[1]),
+                              float(bc[0]), float(bc[1]), int(M), int(n_colloc), float(gamma),
+                              rhs_id, params, _ptr(rhs_values), int(solver),
+                              _ptr(out), _ptr(status), _ptr(fail_count),
+                              _ptr(work), 0 if work is None else work.numel() * 8, _stream(stream), None)
+    _capi.check(rc, "lssvr_enhance_ws")
     return out, status
 
 
@@ -229,9 +256,10 @@ def enhance_shared(x, u, op, M, n_colloc, *, rhs=(POISSON_AMP, POISSON_OMEGA), r
 
 def enhance_profiled(x, u, M, gamma, n_colloc=12, *, rhs=(POISSON_AMP, POISSON_OMEGA),
                      elem_offset=0, ne_global=None, global_domain, bc=(0.0, 0.0),
-                     solver=SOLVER_PRIMAL, out=None, status=None, stream=None):
+                     solver=SOLVER_PRIMAL, out=None, status=None, stream=None, work=None):
     """Same launch as :func:`enhance` but BLOCKING and stamped with the dispatch's own
-    begin/end timestamps; returns the kernel duration in seconds (roofline measurement)."""
+    begin/end timestamps; returns the kernel duration in seconds (roofline measurement; on the
+    two-kernel path above M = 22 the duration of the pair, gap included)."""
     import ctypes
     lib = _capi.load()
     _dev(x, "x")
@@ -243,12 +271,18 @@ def enhance_profiled(x, u, M, gamma, n_colloc=12, *, rhs=(POISSON_AMP, POISSON_O
         ne_global = elem_offset + ne
     out, status = _check_buffers(ne, M, n_colloc, x, out=out, status=status)
     ms = ctypes.c_float(0.0)
-    rc = lib.lssvr_enhance_profiled(_ptr(x), _ptr(u), ne, int(elem_offset), int(ne_global),
-                                    float(global_domain[0]), float(global_domain[1]),
-                                    float(bc[0]), float(bc[1]), int(M), int(n_colloc), float(gamma),
-                                    RHS_SIN, _capi.rhs_params(*rhs), None, int(solver),
-                                    _ptr(out), _ptr(status), _stream(stream), ctypes.byref(ms))
-    _capi.check(rc, "lssvr_enhance_profiled")
+    if work is None:
+        work = workspace(lib, x.device, ne, M, n_colloc, solver)
+    elif work is False:
+        work = None
+    rc = lib.lssvr_enhance_ws(_ptr(x), _ptr(u), ne, int(elem_offset), int(ne_global),
+                              float(global_domain[0]), float(global_domain[1]),
+                              float(bc[0]), float(bc[1]), int(M), int(n_colloc), float(gamma),
+                              RHS_SIN, _capi.rhs_params(*rhs), None, int(solver),
+                              _ptr(out), _ptr(status), None,
+                              _ptr(work), 0 if work is None else work.numel() * 8, _stream(stream),
+                              ctypes.byref(ms))
+    _capi.check(rc, "lssvr_enhance_ws(profiled)")
     return ms.value * 1e-3
 
 
@@ -281,6 +315,11 @@ class StepPlan:
         self.W, self.status = _check_buffers(ne, M, n_colloc, x, out=out, status=status,
                                              fail_count=fail_count)
         self.fail_count = fail_count
+        # above M = 22 lssvr_step is assembly + the workspace-free enhancement kernel (two launches);
+        # with a workspace the enhancement runs as the faster moment / solve pair: three launches
+        # (a private buffer: plans may run concurrently on different streams)
+        nb = int(self.lib.lssvr_enhance_work_bytes(ne, int(M), int(n_colloc), SOLVER_PRIMAL))
+        self._work = torch.empty((nb + 7) // 8, dtype=torch.float64, device=dev) if nb > 0 else None
         self._keep = (x, u, _capi.rhs_params(*rhs))
         self._args = (_ptr(x), _ptr(u), ne, int(elem_offset), int(ne_global),
                       float(global_domain[0]), float(global_domain[1]), float(bc[0]), float(bc[1]),
@@ -288,8 +327,24 @@ class StepPlan:
                       _ptr(self.bands["diag"]), _ptr(self.bands["off"]), _ptr(self.bands["load"]),
                       _ptr(self.W), _ptr(self.status), _ptr(fail_count))
 
+        if self._work is not None:
+            self._asm_args = (_ptr(x), ne, int(nquad), RHS_SIN, self._keep[2], None, None,
+                              _ptr(self.bands["diag"]), _ptr(self.bands["off"]), _ptr(self.bands["load"]),
+                              None, None)
+            self._enh_args = (_ptr(x), _ptr(u), ne, int(elem_offset), int(ne_global),
+                              float(global_domain[0]), float(global_domain[1]), float(bc[0]), float(bc[1]),
+                              int(M), int(n_colloc), float(gamma), RHS_SIN, self._keep[2], None,
+                              SOLVER_PRIMAL, _ptr(self.W), _ptr(self.status), _ptr(fail_count),
+                              _ptr(self._work), self._work.numel() * 8)
+
     def launch(self, stream=None):
-        rc = self.lib.lssvr_step(*self._args, _stream(stream))
+        st = _stream(stream)
+        if self._work is not None:
+            rc = self.lib.lssvr_p1_assemble(*self._asm_args, st)
+            if rc >= 0:
+                rc = self.lib.lssvr_enhance_ws(*self._enh_args, st, None)
+        else:
+            rc = self.lib.lssvr_step(*self._args, st)
         if rc < 0:
             _capi.check(rc, "lssvr_step")
         return self.W, self.status

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LSSVR_ABI_VERSION 2
+#define LSSVR_ABI_VERSION 3
 
 /* error codes */
 #define LSSVR_OK              0
@@ -59,8 +59,10 @@ extern "C" {
                                  the exact minimiser on every BASELINE config  */
 #define LSSVR_SOLVER_PRIMAL_MOMENT 3 /* same algorithm as PRIMAL in the two-phase wave mapping of
                                  csrc/enhance_large_cheb.hip (Chebyshev-moment Gram, four systems
-                                 per wave in the LDL^T); any M, Poisson rows; for A/B measurements:
-                                 half the instructions of PRIMAL_WAVE, 10-20 % slower */
+                                 per wave in the LDL^T) for any M, Poisson rows; for A/B
+                                 measurements.  With a workspace (lssvr_enhance_ws) the two-kernel
+                                 form -- what PRIMAL itself runs above M = 22 -- without one the
+                                 fused single kernel (2 resident waves per SIMD, slower) */
 #define LSSVR_SOLVER_PRIMAL_WAVE 2 /* same algorithm as PRIMAL, forced onto the
                                  wave-per-element / f64-MFMA Gram mapping whatever M is
                                  (PRIMAL picks lane-per-element for M <= 22); for A/B
@@ -111,6 +113,28 @@ int lssvr_enhance(const double* x, const double* u, int64_t ne,
                   int rhs_id, const double* rhs_params_host, const double* rhs_values,
                   int solver_id,
                   double* W, int32_t* status, int32_t* fail_count, void* stream);
+
+/*
+ * lssvr_enhance_ws -- lssvr_enhance with a caller-provided device workspace (the library still
+ * allocates nothing).  Poisson rows above M = 22 then run as TWO kernels -- Chebyshev moments of
+ * the collocation points (96 doubles per element into `work`), then the four-systems-per-wave
+ * solve -- 1.4-1.5x the speed of the single f64-MFMA kernel lssvr_enhance launches without a
+ * workspace.  Every other case behaves exactly like lssvr_enhance.
+ *   lssvr_enhance_work_bytes(ne, M, n_colloc, solver_id)   bytes `work` must hold (0: none needed)
+ *   work / work_bytes      device scratch, contents undefined afterwards; too small or NULL: the
+ *                          workspace-free kernels run
+ *   kernel_ms_host != NULL BLOCKING measurement aid like lssvr_enhance_profiled: the duration of
+ *                          the launch (of the PAIR of kernels, gap included, on the split path)
+ */
+int64_t lssvr_enhance_work_bytes(int64_t ne, int M, int n_colloc, int solver_id);
+int lssvr_enhance_ws(const double* x, const double* u, int64_t ne,
+                     int64_t elem_offset, int64_t ne_global,
+                     double gxmin, double gxmax, double bc_left, double bc_right,
+                     int M, int n_colloc, double gamma,
+                     int rhs_id, const double* rhs_params_host, const double* rhs_values,
+                     int solver_id,
+                     double* W, int32_t* status, int32_t* fail_count,
+                     void* work, int64_t work_bytes, void* stream, float* kernel_ms_host);
 
 /*
  * lssvr_enhance_profiled -- the same launch as lssvr_enhance, stamped with the

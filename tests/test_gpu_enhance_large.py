@@ -157,3 +157,36 @@ def test_moment_wave_mapping_vs_default(dev, M, n, ne):
     W2, _ = ops.enhance(x, _t(values, dev), M, 1e4, n, global_domain=gd, rhs_values=f, solver=ops.SOLVER_PRIMAL_MOMENT)
     torch.cuda.synchronize()
     assert orc.rel_l2_coef(W2.cpu().numpy(), W).max() <= 1e-12
+
+
+def test_workspace_free_entry_matches_two_kernel_path(dev, golden):
+    """Above M = 22 `ops.enhance` takes lssvr_enhance_ws with a workspace (moments kernel + solve
+    kernel); `work=False` -- what the workspace-free C entry lssvr_enhance launches -- runs the
+    single f64-MFMA kernel.  Same minimiser: both against the golden truth and each other; the
+    fused StepPlan (assembly + enhancement) of both degrees classes as well."""
+    import torch
+    from hybrid_fem_lssvr_amd import ops
+    g = golden("G5_ne24_M33_n64")
+    ne, M, n, gamma = int(g["ne"]), int(g["M"]), int(g["n"]), float(g["gamma"])
+    nodes = np.linspace(-1.0, 1.0, ne + 1)
+    values = orc.fem_p1_solve(nodes)
+    values[g["elements"]] = g["values_sel"][:, 0]
+    values[g["elements"] + 1] = g["values_sel"][:, 1]
+    x, u = _t(nodes, dev), _t(values, dev)
+    W2, s2 = ops.enhance(x, u, M, gamma, n, global_domain=(-1.0, 1.0))
+    W1, s1 = ops.enhance(x, u, M, gamma, n, global_domain=(-1.0, 1.0), work=False)
+    plan = ops.StepPlan(x, u, M, gamma, n, global_domain=(-1.0, 1.0))
+    W3, s3 = plan.launch()
+    torch.cuda.synchronize()
+    assert int(s1.sum()) == 0 and int(s2.sum()) == 0 and int(s3.sum()) == 0
+    for W in (W1, W2, W3):
+        assert orc.rel_l2_coef(W.cpu().numpy()[g["elements"]], g["coef_truth"]).max() <= TOL_TRUTH
+    assert orc.rel_l2_coef(W1.cpu().numpy(), W2.cpu().numpy()).max() <= 1e-12
+    assert torch.equal(W2, W3)
+    bands = orc.p1_scatter(*orc.p1_assemble_local(nodes))
+    assert np.allclose(plan.bands["diag"].cpu().numpy(), bands[0], rtol=1e-15)
+    # a workspace that is too small falls back to the workspace-free kernel instead of overrunning it
+    small = torch.empty(16, dtype=torch.float64, device=dev)
+    W4, _ = ops.enhance(x, u, M, gamma, n, global_domain=(-1.0, 1.0), work=small)
+    torch.cuda.synchronize()
+    assert torch.equal(W4, W1)

@@ -82,8 +82,12 @@ def test_subset_leaves_other_rows_alone(dev):
         touched[[129, 0, 64, 3, 77]] = True
         assert np.all(Wh[~touched] == 7.0) and np.all(sth[~touched] == -5)
         assert np.all(Wh[touched][:, M:] == 7.0) and np.all(sth[touched] == 0)
-        Wfull, _ = ops.enhance(x, u, M, 1e4, n, global_domain=gd)
+        # (a subset launch runs the workspace-free kernels: bit-identical to `work=False`, and
+        # within rounding of the two-kernel default above M = 22)
+        Wfull, _ = ops.enhance(x, u, M, 1e4, n, global_domain=gd, work=False)
         assert np.array_equal(Wh[touched][:, :M], Wfull.cpu().numpy()[touched])
+        Wdef, _ = ops.enhance(x, u, M, 1e4, n, global_domain=gd)
+        assert orc.rel_l2_coef(Wh[touched][:, :M], Wdef.cpu().numpy()[touched]).max() <= 1e-12
 
 
 def test_subset_argument_errors(dev):
@@ -125,5 +129,5 @@ def test_subset_out_of_range_ids_touch_nothing(dev):
         good[[6, 18, 90]] = True
         assert np.all(Wh[~good] == 7.0) and np.all(sth[~good] == -5)
         assert np.all(sth[good] == 0)
-        Wfull, _ = ops.enhance(x, u, M, 1e4, n, global_domain=gd)
+        Wfull, _ = ops.enhance(x, u, M, 1e4, n, global_domain=gd, work=False)
         assert np.array_equal(Wh[good], Wfull.cpu().numpy()[[5, 17, 89]])
