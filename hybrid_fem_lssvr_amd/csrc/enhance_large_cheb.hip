@@ -28,12 +28,12 @@
 //     cross-row permutes), DPP back-substitution, v = Y z through LDS, w_{0,1} by row reductions.
 // No MFMA, no operand staging, no accumulator transposition -- and half the instructions of
 // enhance_large.hip (880 against 980 vector + 160 matrix instructions per element).  MEASURED
-// (MI355X, M = 33, 64 points): 407-465 us at 1e5 elements and 3.3-3.9 ms at 1e6 against 352-387 us
-// and 3.2 ms: the 128 registers of the two-columns-per-lane factorisation leave 2 resident waves
-// per SIMD where enhance_large.hip runs 3, and a wave of these dependent FP64 / DPP chains issues
-// one instruction per 16-20 cycles whatever the kernel (rocprofv3: 50 % of the wave-cycles in
-// s_waitcnt at 2 waves against 23 % at 3).  It is therefore an opt-in solver
-// (LSSVR_SOLVER_PRIMAL_MOMENT), kept for the A/B; DESIGN.md section 9 has the numbers.
+// (MI355X, M = 33, 64 points): this FUSED kernel 407-490 us at 1e5 elements and 3.3-3.9 ms at 1e6
+// against 352-395 us and 3.2 ms of enhance_large.hip -- the 91 accumulators of phase 1 and the 128
+// column registers of phase 2 leave 2 resident waves per SIMD and make the waves long.  The SAME
+// two phases as two kernels with a workspace in between (moments_kernel + solve4_kernel, bottom of
+// this file) take 242 us and 2.04 ms and are what LSSVR_SOLVER_PRIMAL runs above M = 22; the
+// fused kernel stays reachable as LSSVR_SOLVER_PRIMAL_MOMENT without a workspace.
 #include "cheb_tables.hpp"
 #include "lssvr_device.hpp"
 #include "lssvr_kernels.hpp"
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(64, 2) void enhance_large_cheb_kernel(EnhanceArgs p
 // lane and fits the register budget of three resident waves per SIMD, its waves are short (four
 // elements each) and the tables sit in LDS -- what the fused kernel above lacks.
 // This pair is the DEFAULT for Poisson rows above M = 22 whenever the caller passes a workspace
-// (lssvr_enhance_ws): 263 us at 1e5 elements and 2.3 ms at 1e6 (M = 33, 64 points) against
+// (lssvr_enhance_ws): 242 us at 1e5 elements and 2.04 ms at 1e6 (M = 33, 64 points) against
 // 352-395 us and 3.2 ms of enhance_large_kernel.
 // =============================================================================================
 constexpr int kWsStride = 96;            // per element: m_0..m_60 at [0, 61), r_0..r_30 at [64, 95)
@@ -600,11 +600,12 @@ __global__ __launch_bounds__(256, 2) void moments_kernel(EnhanceArgs p, double* 
 // Phase 2 alone: a workgroup of four waves = sixteen elements (four per wave); the moments come
 // from the workspace through LDS, the tables N and Y are copied to LDS once per workgroup (read
 // from the device tables they cost every wave ~60 exposed L1/L2 round trips: 58 % of its life in
-// s_waitcnt).
+// s_waitcnt).  Two resident waves per SIMD without spills (216 VGPRs) beat three with 73 spilled
+// registers (242 against 263 us at 1e5 elements).
 constexpr int kS4Stride = 112;           // LDS per element: 96 + 16 (groups of a half on disjoint banks)
 constexpr int kS4Waves = 4;
 constexpr int kS4WaveDoubles = 4 * kS4Stride + 4 * 64;
-__global__ __launch_bounds__(64 * kS4Waves, 3) void solve4_kernel(EnhanceArgs p,
+__global__ __launch_bounds__(64 * kS4Waves, 2) void solve4_kernel(EnhanceArgs p,
                                                                    const double* __restrict__ ws,
                                                                    unsigned nxcd) {
   __shared__ double2_t lds2[(32 * 32 + 32 * 64 + kS4Waves * kS4WaveDoubles) / 2];
