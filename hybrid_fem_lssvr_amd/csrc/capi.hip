@@ -99,13 +99,13 @@ int enhance_dispatch(const lssvr::EnhanceArgs& a, int solver_id, hipStream_t s,
   // large degree, Poisson rows, workspace given: Chebyshev moments + four-systems-per-wave solve as
   // two kernels (1.4-1.5x the speed of the MFMA kernel)
   if (solver_id == LSSVR_SOLVER_PRIMAL && !a.a_values && !a.elem_ids && work &&
-      work_bytes >= lssvr::enhance_moment_ws_bytes(a.ne))
+      work_bytes >= lssvr::enhance_moment_ws_bytes(a.ne, a.M, a.n))
     return check_launch(lssvr::enhance_large_split(a, work, s, o), "enhance_large_split");
   // otherwise the direct Gram on the f64 matrix cores; LSSVR_SOLVER_PRIMAL_MOMENT forces the moment
   // form (fused single kernel without a workspace: 2 resident waves per SIMD, slower)
   if (solver_id == LSSVR_SOLVER_PRIMAL_MOMENT) {
     if (a.a_values) return fail(LSSVR_ERR_SOLVER, "LSSVR_SOLVER_PRIMAL_MOMENT: Poisson rows only");
-    if (work && work_bytes >= lssvr::enhance_moment_ws_bytes(a.ne) && !a.elem_ids)
+    if (work && work_bytes >= lssvr::enhance_moment_ws_bytes(a.ne, a.M, a.n) && !a.elem_ids)
       return check_launch(lssvr::enhance_large_split(a, work, s, o), "enhance_large_split");
     return check_launch(lssvr::enhance_large_cheb(a, s, o), "enhance_large_cheb");
   }
@@ -140,10 +140,9 @@ int lssvr_enhance(const double* x, const double* u, int64_t ne, int64_t elem_off
 }
 
 int64_t lssvr_enhance_work_bytes(int64_t ne, int M, int n_colloc, int solver_id) {
-  (void)n_colloc;
   if (ne <= 0 || M <= lssvr::kSmallMaxM) return 0;
   if (solver_id != LSSVR_SOLVER_PRIMAL && solver_id != LSSVR_SOLVER_PRIMAL_MOMENT) return 0;
-  return lssvr::enhance_moment_ws_bytes(ne);
+  return lssvr::enhance_moment_ws_bytes(ne, M, n_colloc);
 }
 
 int lssvr_enhance_ws(const double* x, const double* u, int64_t ne, int64_t elem_offset,

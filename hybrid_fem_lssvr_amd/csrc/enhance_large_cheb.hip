@@ -108,12 +108,19 @@ __device__ const ChebDeviceTables kTab = make_cheb_device_tables();
 // ---------------------------------------------------------------------------------------------
 // Ntab (row stride 32) / Ytab (row stride 64): the device tables or LDS copies of them.
 // PRE: the element's a, b, g_l, g_r come with the moments (mo[61..63], ro[31]; split kernels).
-template <bool PRE>
+// MODE (iterative refinement of the near-square regime, refine_steps() below): 0 = plain solve;
+// 1 = also store the Chebyshev coefficients z to zout[0..32); 2 = a refinement step: ro[] holds
+// sum_k T_i(t_k) e_k of the point residual e = phi2 - 2 T zold (residual_kernel), the ridge part
+// of the residual is formed here from the ridge entries of S as they are built, the solve gives
+// the correction and z = zold + dz goes on to W and to zout.
+template <bool PRE, int MODE = 0>
 __device__ __forceinline__ void solve_four(const EnhanceArgs& p, const int lane, const int64_t e_raw,
                                            const double* __restrict__ mo,
                                            const double* __restrict__ ro, double* __restrict__ Z,
                                            const double* __restrict__ Ntab,
-                                           const double* __restrict__ Ytab) {
+                                           const double* __restrict__ Ytab,
+                                           const double* __restrict__ zold = nullptr,
+                                           double* __restrict__ zout = nullptr) {
   const int M = p.M, MR = M - 2;
   int q = lane & 15;
   asm volatile("" : "+v"(q));      // (keeps phase 2's lane constants out of phase 1's register budget)
@@ -228,22 +235,25 @@ __device__ __forceinline__ void solve_four(const EnhanceArgs& p, const int lane,
     if (!inB) C0B = C1B = 0.0;
 
     // ---- right-hand side entries of this lane's columns, then the two columns of S2 --------------
-    double rhsA, rhsB;
-    if (any_slow) {
-      rhsA = fma(eps2, fma(C0zA, d0, C1zA * d1), ro[cA]);
-      rhsB = fma(eps2, fma(C0zB, d0, C1zB * d1), ro[cB]);
-    } else {
-      const double e_d = eps2 * (q_even ? d0 : d1);
-      const double q_c = eps2 * (q_even ? fma(del, d1, -(sig * d0)) : fma(del, d0, -(sig * d1)));
-      rhsA = fma(bA, q_c, fma(alA, e_d, ro[cA]));
-      rhsB = fma(bB, q_c, fma(alB, e_d, ro[cB]));
+    double rhsA = 0.0, rhsB = 0.0;
+    [[maybe_unused]] double rzA = 0.0, rzB = 0.0;      // MODE 2: (ridge part of S) zold, this lane's columns
+    const double e_d = eps2 * (q_even ? d0 : d1);
+    const double q_c = eps2 * (q_even ? fma(del, d1, -(sig * d0)) : fma(del, d0, -(sig * d1)));
+    if constexpr (MODE != 2) {
+      if (any_slow) {
+        rhsA = fma(eps2, fma(C0zA, d0, C1zA * d1), ro[cA]);
+        rhsB = fma(eps2, fma(C0zB, d0, C1zB * d1), ro[cB]);
+      } else {
+        rhsA = fma(bA, q_c, fma(alA, e_d, ro[cA]));
+        rhsB = fma(bB, q_c, fma(alB, e_d, ro[cB]));
+      }
+      if (!inA) rhsA = 0.0;
+      if (!inB) rhsB = 0.0;
+      wave_lds_sync();                 // previous round's readers of Z are done
+      Z[cA] = rhsA;
+      Z[cB] = rhsB;
+      wave_lds_sync();
     }
-    if (!inA) rhsA = 0.0;
-    if (!inB) rhsB = 0.0;
-    wave_lds_sync();                 // previous round's readers of Z are done
-    Z[cA] = rhsA;
-    Z[cB] = rhsB;
-    wave_lds_sync();
     double A[kLP], B[kLP];
     {
       const double es = eps2 * sig, ed = eps2 * del;
@@ -258,7 +268,7 @@ __device__ __forceinline__ void solve_four(const EnhanceArgs& p, const int lane,
       // one column at a time (half the coefficient registers live): first-order ridge
       //   same parity:  eps2 (N_ic + al_i al_c) - es (al_i b_c + b_i al_c),   opposite:  ed (al_i b_c + b_i al_c)
       auto column = [&](double (&X)[kLP], const int cx, const double alc, const double bc,
-                        const double C0z, const double C1z, const bool inx) {
+                        const double C0z, const double C1z, const bool inx, [[maybe_unused]] double& rz) {
         const double u1 = fma(eps2, alc, -(es * bc)), u2 = -(es * alc), u3 = ed * bc, u4 = ed * alc;
         const double Xe = q_even ? u1 : u3, Ye = q_even ? u2 : u4;       // even rows
         const double Xo = q_even ? u3 : u1, Yo = q_even ? u4 : u2;       // odd rows
@@ -269,8 +279,12 @@ __device__ __forceinline__ void solve_four(const EnhanceArgs& p, const int lane,
             // C_z[., i]: lane (i & 15) of the row, first / second column
             const int si = (lane & ~15) + (i & 15);
             const double f0 = __shfl(i < 16 ? C0zA : C0zB, si), f1 = __shfl(i < 16 ? C1zA : C1zB, si);
+            if constexpr (MODE == 2) rz = fma(eps2 * fma(f0, C0z, fma(f1, C1z, X[i])), zold[i], rz);
             v = fma(eps2, fma(f0, C0z, fma(f1, C1z, X[i])), v);
           } else {
+            if constexpr (MODE == 2)
+              rz = fma(fma(cheb::kB[i], (i & 1) ? Yo : Ye, fma(cheb::kAlpha[i], (i & 1) ? Xo : Xe, eps2 * X[i])),
+                       zold[i], rz);
             v = fma(eps2, X[i], v);
             v = fma(cheb::kAlpha[i], (i & 1) ? Xo : Xe, v);
             v = fma(cheb::kB[i], (i & 1) ? Yo : Ye, v);
@@ -278,8 +292,19 @@ __device__ __forceinline__ void solve_four(const EnhanceArgs& p, const int lane,
           X[i] = inx ? v : 0.0;
         }
       };
-      column(A, cA, alA, bA, C0zA, C1zA, inA);
-      column(B, cBc, alB, bB, C0zB, C1zB, inB);
+      column(A, cA, alA, bA, C0zA, C1zA, inA, rzA);
+      column(B, cBc, alB, bB, C0zB, C1zB, inB, rzB);
+      if constexpr (MODE == 2) {
+        // residual of the normal equations: the Gram part through the points (ro), the ridge part here
+        const double ridA = any_slow ? eps2 * fma(C0zA, d0, C1zA * d1) : fma(bA, q_c, alA * e_d);
+        const double ridB = any_slow ? eps2 * fma(C0zB, d0, C1zB * d1) : fma(bB, q_c, alB * e_d);
+        rhsA = inA ? ro[cA] + (ridA - rzA) : 0.0;
+        rhsB = inB ? ro[cB] + (ridB - rzB) : 0.0;
+        wave_lds_sync();
+        Z[cA] = rhsA;
+        Z[cB] = rhsB;
+        wave_lds_sync();
+      }
       if (cB == kRhsRow) {           // column 31 carries the right-hand side as a column
 #pragma unroll
         for (int i = 0; i < kLP - 1; ++i) B[i] = Z[i];
@@ -292,6 +317,16 @@ __device__ __forceinline__ void solve_four(const EnhanceArgs& p, const int lane,
     bool lane_ok;
     double zA, zB;
     ldlt_solve_dpp4(A, B, q, MR, lane_ok, zA, zB);
+    if constexpr (MODE == 2) {
+      zA += zold[cA];
+      zB += zold[cB];                  // (zold[31] = 0)
+    }
+    if constexpr (MODE >= 1) {
+      if (e_raw < p.ne) {
+        zout[cA] = inA ? zA : 0.0;
+        zout[cB] = inB ? zB : 0.0;
+      }
+    }
     // v = Y z (bubble Legendre coefficients): v_j = sum_{i >= j, i = j mod 2} Y[j][i] z_i
     wave_lds_sync();
     Z[cA] = inA ? zA : 0.0;
@@ -601,14 +636,18 @@ __global__ __launch_bounds__(256, 2) void moments_kernel(EnhanceArgs p, double* 
 // from the workspace through LDS, the tables N and Y are copied to LDS once per workgroup (read
 // from the device tables they cost every wave ~60 exposed L1/L2 round trips: 58 % of its life in
 // s_waitcnt).  Two resident waves per SIMD without spills (216 VGPRs) beat three with 73 spilled
-// registers (242 against 263 us at 1e5 elements).
+// registers (242 against 263 us at 1e5 elements).  MODE: see solve_four; zws = 32 doubles per element.
 constexpr int kS4Stride = 112;           // LDS per element: 96 + 16 (groups of a half on disjoint banks)
 constexpr int kS4Waves = 4;
 constexpr int kS4WaveDoubles = 4 * kS4Stride + 4 * 64;
+constexpr int kZStride = 32;
+template <int MODE>
 __global__ __launch_bounds__(64 * kS4Waves, 2) void solve4_kernel(EnhanceArgs p,
                                                                    const double* __restrict__ ws,
+                                                                   double* __restrict__ zws,
                                                                    unsigned nxcd) {
-  __shared__ double2_t lds2[(32 * 32 + 32 * 64 + kS4Waves * kS4WaveDoubles) / 2];
+  __shared__ double2_t lds2[(32 * 32 + 32 * 64 + kS4Waves * kS4WaveDoubles +
+                             (MODE == 2 ? kS4Waves * 4 * kZStride : 0)) / 2];
   double* const Nl = reinterpret_cast<double*>(lds2);
   double* const Yl = Nl + 32 * 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -630,10 +669,107 @@ __global__ __launch_bounds__(64 * kS4Waves, 2) void solve4_kernel(EnhanceArgs p,
     const int64_t e = (Ec + el < p.ne) ? Ec + el : p.ne - 1;
     lds[el * kS4Stride + j] = ws[e * kWsStride + j];
   }
-  __syncthreads();
   const int g = lane >> 4;
+  [[maybe_unused]] double* zl = nullptr;
+  if constexpr (MODE == 2) {
+    zl = Yl + 32 * 64 + kS4Waves * kS4WaveDoubles + wave * (4 * kZStride);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int idx = k * 64 + lane;                // 128 = 4 x 32 doubles
+      const int el = idx / kZStride, j = idx % kZStride;
+      const int64_t e = (Ec + el < p.ne) ? Ec + el : p.ne - 1;
+      zl[idx] = zws[e * kZStride + j];
+    }
+    zl += g * kZStride;
+  }
+  __syncthreads();
   double* const Z = lds + 4 * kS4Stride + g * 64;
-  solve_four<true>(p, lane, E0 + g, lds + g * kS4Stride, lds + g * kS4Stride + 64, Z, Nl, Yl);
+  const int64_t eo = (E0 + g < p.ne) ? E0 + g : p.ne - 1;
+  solve_four<true, MODE>(p, lane, E0 + g, lds + g * kS4Stride, lds + g * kS4Stride + 64, Z, Nl, Yl, zl,
+                         MODE >= 1 ? zws + eo * kZStride : nullptr);
+}
+
+// Point residual of a refinement step, ONE ELEMENT PER LANE like moments_kernel:
+//   e_k = phi2_k - 2 sum_i z_i T_i(t_k)  (Clenshaw),   r_i = sum_k T_i(t_k) e_k  -> ws[e][64 + i]
+// (the corrected semi-normal equations: the residual goes through the rows, never through the Gram
+// matrix, so the correction recovers the digits the normal equations lost -- DESIGN.md section 2).
+template <int RHS>
+__global__ __launch_bounds__(256) void residual_kernel(EnhanceArgs p, double* __restrict__ ws,
+                                                       const double* __restrict__ zws) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = e < p.ne;
+  const int64_t ec = live ? e : p.ne - 1;
+  const int64_t id = ec;                       // (no subset form of the two-kernel path)
+  const int n = p.n;
+  const double a = p.x[id];
+  const double b = p.x[id + 1];
+  const DomainMap dm = map_params(a, b);
+  const double step = dm.oldlen / (double)(n - 1);
+  const double hh = 0.5 * dm.oldlen;
+  const double inv_scl2 = hh * hh;
+  double z[kTop + 1], rr[kTop + 1];
+#pragma unroll
+  for (int d = 0; d <= kTop; ++d) {
+    z[d] = zws[ec * kZStride + d];
+    rr[d] = 0.0;
+  }
+  double rs = 0.0, rc = 1.0, sd = 0.0, cd = 1.0, th0 = 0.0, dth = 0.0, kappa = 0.0;
+  if constexpr (RHS == LSSVR_RHS_SIN) {
+    dth = p.rhs_omega * step;
+    sincos_tab(dth, sd, cd, p.trig);
+    kappa = -2.0 * (p.rhs_amp * inv_scl2);
+  }
+  [[maybe_unused]] const double fscale = -2.0 * inv_scl2;
+  for (int k0 = 0; k0 < n; k0 += kReseedLarge) {
+    if constexpr (RHS == LSSVR_RHS_SIN) {
+      const double x0 = (k0 == 0) ? a : fma((double)k0, step, a);
+      th0 = p.rhs_omega * x0;
+      sincos_tab(th0, rs, rc, p.trig);
+      rs *= kappa;
+      rc *= kappa;
+    }
+    const int k1 = min(k0 + kReseedLarge, n);
+    for (int k = k0; k < k1; ++k) {
+      const double xk = (k == n - 1) ? b : (double)k * step + a;
+      const double tk = dm.off + dm.scl * xk;
+      double phi2;                                     // (the same values as moments_kernel's)
+      if constexpr (RHS == LSSVR_RHS_SIN) {
+        const double arg = p.rhs_omega * xk;
+        const double delta = fma(-(double)(k - k0), dth, arg - th0);
+        phi2 = fma(rc, delta, rs);
+        if (__any(!(fabs(delta) < 1.0e-7))) phi2 = kappa * sin_tab(arg, p.trig);
+        const double rs_next = fma(rs, cd, rc * sd);
+        rc = fma(rc, cd, -(rs * sd));
+        rs = rs_next;
+      } else {
+        phi2 = p.rhs_values[ec * n + k] * fscale;
+      }
+      const double tt = tk + tk;
+      double b1 = 0.0, b2 = 0.0;
+#pragma unroll
+      for (int d = kTop; d >= 1; --d) {
+        const double b0 = fma(tt, b1, z[d]) - b2;
+        b2 = b1;
+        b1 = b0;
+      }
+      const double Tz = fma(tk, b1, z[0]) - b2;
+      const double ek = fma(-2.0, Tz, phi2);
+      double Tm2 = 1.0, Tm1 = tk;
+      rr[0] += ek;
+      rr[1] = fma(Tm1, ek, rr[1]);
+#pragma unroll
+      for (int d = 2; d <= kTop; ++d) {
+        const double Td = fma(tt, Tm1, -Tm2);
+        rr[d] = fma(Td, ek, rr[d]);
+        Tm2 = Tm1;
+        Tm1 = Td;
+      }
+    }
+  }
+  if (!live) return;
+  double* const o = ws + e * kWsStride + 64;
+#pragma unroll
+  for (int i = 0; i <= kTop; ++i) o[i] = rr[i];
 }
 
 hipError_t enhance_large_cheb(const EnhanceArgs& a, hipStream_t s, const LaunchOpts* o) {
@@ -648,31 +784,59 @@ hipError_t enhance_large_cheb(const EnhanceArgs& a, hipStream_t s, const LaunchO
   return launch(enhance_large_cheb_kernel<LSSVR_RHS_ARRAY>, grid, block, s, o, a, nxcd);
 }
 
-int64_t enhance_moment_ws_bytes(int64_t ne) { return ne * kWsStride * (int64_t)sizeof(double); }
+// Refinement steps of the two-kernel path by the excess of collocation points over bubble
+// coefficients: equispaced points with n ~ M-2 make the normal equations lose up to ten digits
+// (3e-6 at M = 33, n = 31); each step of the corrected semi-normal equations wins back about three
+// (scripts/proto/qr_nearsquare.py; measured envelope in DESIGN.md section 2).
+int enhance_refine_steps(int M, int n) {
+  const int excess = n - (M - 2);
+  if (M <= kSmallMaxM || excess < 0) return 0;
+  return excess <= 1 ? 3 : excess <= 4 ? 2 : excess <= 14 ? 1 : 0;
+}
+
+int64_t enhance_moment_ws_bytes(int64_t ne, int M, int n) {
+  return ne * (kWsStride + (enhance_refine_steps(M, n) > 0 ? kZStride : 0)) * (int64_t)sizeof(double);
+}
 
 hipError_t enhance_large_split(const EnhanceArgs& a, void* work, hipStream_t s, const LaunchOpts* o) {
-  if (a.M - 2 + 1 > kLP || a.a_values || !work) return hipErrorInvalidValue;
+  if (a.M - 2 + 1 > kLP || a.a_values || a.elem_ids || !work) return hipErrorInvalidValue;
   double* const ws = static_cast<double*>(work);
+  double* const zws = ws + a.ne * kWsStride;
+  const int steps = enhance_refine_steps(a.M, a.n);
   const unsigned nxcd = xcd_count();
   const unsigned b1 = (unsigned)((a.ne + 255) / 256);
   int64_t blocks = (a.ne + 4 * kS4Waves - 1) / (4 * kS4Waves);
   blocks = (blocks + nxcd - 1) / nxcd * nxcd;
   if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-  // profiled launches: the start stamp of the first kernel and the stop stamp of the second --
-  // the duration reported is that of the PAIR, gap included
+  const dim3 g1(b1), t1(256), g2((unsigned)blocks), t2(64 * kS4Waves);
+  // profiled launches: the start stamp of the first kernel and the stop stamp of the last --
+  // the duration reported is that of the whole sequence, gaps included
   const bool prof = o && o->start && o->stop;
-  if (a.rhs_id == LSSVR_RHS_SIN) {
-    if (prof) hipExtLaunchKernelGGL(moments_kernel<LSSVR_RHS_SIN>, dim3(b1), dim3(256), 0, s, o->start, nullptr, 0, a, ws);
-    else hipLaunchKernelGGL(moments_kernel<LSSVR_RHS_SIN>, dim3(b1), dim3(256), 0, s, a, ws);
-  } else {
-    if (prof) hipExtLaunchKernelGGL(moments_kernel<LSSVR_RHS_ARRAY>, dim3(b1), dim3(256), 0, s, o->start, nullptr, 0, a, ws);
-    else hipLaunchKernelGGL(moments_kernel<LSSVR_RHS_ARRAY>, dim3(b1), dim3(256), 0, s, a, ws);
-  }
-  hipError_t e = hipGetLastError();
+  const bool sine = a.rhs_id == LSSVR_RHS_SIN;
+  // (plain launches unless stamped: the hipExt entry only where an event is attached)
+  auto go = [&](auto kernel, dim3 g, dim3 t, hipEvent_t ev_start, hipEvent_t ev_stop, auto... args) {
+    if (ev_start || ev_stop) hipExtLaunchKernelGGL(kernel, g, t, 0, s, ev_start, ev_stop, 0, args...);
+    else hipLaunchKernelGGL(kernel, g, t, 0, s, args...);
+    return hipGetLastError();
+  };
+  hipEvent_t const ev0 = prof ? o->start : nullptr, ev1 = prof ? o->stop : nullptr;
+  const double* const cws = ws;
+  const double* const czws = zws;
+  hipError_t e = sine ? go(moments_kernel<LSSVR_RHS_SIN>, g1, t1, ev0, nullptr, a, ws)
+                      : go(moments_kernel<LSSVR_RHS_ARRAY>, g1, t1, ev0, nullptr, a, ws);
   if (e != hipSuccess) return e;
-  if (prof) hipExtLaunchKernelGGL(solve4_kernel, dim3((unsigned)blocks), dim3(64 * kS4Waves), 0, s, nullptr, o->stop, 0, a, (const double*)ws, nxcd);
-  else hipLaunchKernelGGL(solve4_kernel, dim3((unsigned)blocks), dim3(64 * kS4Waves), 0, s, a, (const double*)ws, nxcd);
-  return hipGetLastError();
+  if (steps == 0) return go(solve4_kernel<0>, g2, t2, nullptr, ev1, a, cws, (double*)nullptr, nxcd);
+  EnhanceArgs quiet = a;           // failures are counted once, by the last pass
+  quiet.fail_count = nullptr;
+  if ((e = go(solve4_kernel<1>, g2, t2, nullptr, nullptr, quiet, cws, zws, nxcd)) != hipSuccess) return e;
+  for (int it = 1; it <= steps; ++it) {
+    e = sine ? go(residual_kernel<LSSVR_RHS_SIN>, g1, t1, nullptr, nullptr, a, ws, czws)
+             : go(residual_kernel<LSSVR_RHS_ARRAY>, g1, t1, nullptr, nullptr, a, ws, czws);
+    if (e != hipSuccess) return e;
+    e = go(solve4_kernel<2>, g2, t2, nullptr, it == steps ? ev1 : nullptr, it == steps ? a : quiet, cws, zws, nxcd);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 
 }  // namespace lssvr

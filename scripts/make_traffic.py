@@ -29,8 +29,9 @@ def kernel_bytes(fetch_dir, write_dir, want, probe=None):
             cal = probe_doubles * 8.0 / (pv[0] * 1024.0) if pv else None
         else:
             cal = probe[name]
-        kv = [v for (k, c), v in m.items() if want in k and c == ctr]
-        out[name] = (kv[0] if kv else None, cal)
+        wants = want if isinstance(want, (tuple, list)) else (want,)
+        kv = [[v for (k, c), v in m.items() if w in k and c == ctr] for w in wants]
+        out[name] = (sum(v[0] for v in kv) if all(kv) else None, cal)      # several kernels: their sum
     return out
 
 
@@ -40,9 +41,11 @@ res = {"_how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes
 small = kernel_bytes(prof + "/fetch", prof + "/write", "enhance_small_kernel")
 cal = {"fetch": small["fetch"][1], "write": small["write"][1]}
 res["_calibration_bytes_per_counted_byte"] = cal
-large = kernel_bytes(prof + "/fetchL", prof + "/writeL", "enhance_large_kernel", probe=cal)
+large = kernel_bytes(prof + "/fetchL", prof + "/writeL", ("moments_kernel", "solve4_kernel"), probe=cal)
+mfma = kernel_bytes(prof + "/fetchLm", prof + "/writeLm", "enhance_large_kernel", probe=cal)
 shared = kernel_bytes(prof + "/fetchS", prof + "/writeS", "enhance_shared_kernel", probe=cal)
 for key, kb, alg in (("M9_n16_ne100008", small, 88 * 100008), ("M33_n64_ne100000", large, 280 * 100000),
+                     ("M33_n64_ne100000_mfma_kernel", mfma, 280 * 100000),
                      ("shared_M9_n16_ne10000000", shared, 88 * 10000000)):
     f, w = kb["fetch"][0], kb["write"][0]
     if f is None or w is None or cal["fetch"] is None:

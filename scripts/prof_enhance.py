@@ -1,6 +1,7 @@
 """Run only the kernels of interest a few times (target for rocprofv3 --pmc / --kernel-trace).
 
-usage: prof_enhance.py ne,M,n [reps] [solver] [wide|narrow] [probe_doubles]
+usage: prof_enhance.py ne,M,n [reps] [solver] [wide|narrow] [probe_doubles] [nowork]
+(nowork: no workspace is handed over, so degree > 21 runs its single-kernel variants)
 """
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,6 +13,7 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 solver = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 domain = sys.argv[4] if len(sys.argv) > 4 else "wide"
 probe = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+work = False if (len(sys.argv) > 6 and sys.argv[6] == "nowork") else None
 dev = torch.device("cuda:0")
 lo, hi = (-ne / 24.0, ne / 24.0) if domain == "wide" else (-1.0, 1.0)
 nodes = np.arange(ne + 1, dtype=np.float64) * ((hi - lo) / ne) + lo
@@ -21,7 +23,7 @@ u = torch.sin(np.pi * x)
 W = torch.empty((ne, M), dtype=torch.float64, device=dev)
 st = torch.empty(ne, dtype=torch.int32, device=dev)
 for _ in range(reps):
-    ops.enhance(x, u, M, 1e4, n, out=W, status=st, global_domain=(lo, hi), solver=solver)
+    ops.enhance(x, u, M, 1e4, n, out=W, status=st, global_domain=(lo, hi), solver=solver, work=work)
 torch.cuda.synchronize()
 if probe:
     src = torch.zeros(probe, dtype=torch.float64, device=dev)

@@ -190,3 +190,68 @@ def test_workspace_free_entry_matches_two_kernel_path(dev, golden):
     W4, _ = ops.enhance(x, u, M, gamma, n, global_domain=(-1.0, 1.0), work=small)
     torch.cuda.synchronize()
     assert torch.equal(W4, W1)
+
+
+# (M, n, h, bar of the refined two-kernel path, floor of the unrefined single kernel): numbers of
+# scripts/proto/qr_nearsquare.py and of the first GPU run; the bar is ~5x what was measured.
+NEAR_SQUARE = [
+    (33, 31, 1.0 / 12, 3e-13, 1e-8),     # measured on the MI355X: refined 4.8e-14 (3 steps), single kernel 1.1e-6
+    (33, 32, 1.0 / 12, 1e-14, 1e-11),    # 7.5e-16 / 2.1e-8 (2 steps)
+    (33, 33, 1.0 / 12, 1e-14, 1e-12),
+    (33, 35, 1.0 / 12, 1e-14, 1e-13),
+    (33, 38, 1.0 / 12, 1e-14, 0.0),      # 1 step
+    (33, 44, 1.0 / 12, 1e-14, 0.0),
+    (28, 26, 1.0 / 12, 1e-14, 1e-13),
+    (24, 22, 1.0 / 12, 1e-14, 0.0),
+    (33, 33, 0.5, 2e-13, 1e-10),         # 3.6e-14 / 1.2e-7: coarse elements, the problem's own conditioning shows
+    (33, 36, 0.5, 1e-14, 1e-12),
+]
+
+
+@pytest.mark.parametrize("M,n,h,bar,plain_floor", NEAR_SQUARE)
+def test_near_square_refinement(dev, M, n, h, bar, plain_floor):
+    """About as many equispaced collocation points as bubble coefficients (n = M-2 ... M+12): the
+    normal equations lose up to ten digits (3e-6 at M = 33, n = 31); the
+    two-kernel path of lssvr_enhance_ws follows the solve with 1-3 steps of the corrected
+    semi-normal equations (point residual through the rows: residual_kernel + solve4_kernel<2>) and
+    meets the 60-digit minimiser again.  `plain_floor` > 0: the unrefined single kernel (work=False)
+    is demonstrably worse there -- the test would notice the refinement silently not running."""
+    if not cf.HAVE_MP:
+        pytest.skip("mpmath missing")
+    from hybrid_fem_lssvr_amd import _capi
+    ne = int(round(2.0 / h))
+    nodes = np.linspace(-1.0, 1.0, ne + 1)
+    values = np.sin(np.pi * nodes)
+    lib = _capi.load()
+    steps_expected = 3 if n - (M - 2) <= 1 else 2 if n - (M - 2) <= 4 else 1
+    need = lib.lssvr_enhance_work_bytes(ne, M, n, 0)
+    assert need == ne * (96 + 32) * 8, (need, steps_expected)
+    W, st = _enhance(dev, nodes, values, M, 1e4, n, global_domain=(-1.0, 1.0))
+    assert np.all(st == 0)
+    sel = sorted({0, ne // 3, ne // 2, ne - 1})
+    tr = cf.truth_all(nodes, values, M, 1e4, n, orc.poisson_rhs, (-1.0, 1.0), sel)
+    err = orc.rel_l2_coef(W[sel], tr).max()
+    assert err <= bar, err
+    W0, st0 = _enhance(dev, nodes, values, M, 1e4, n, global_domain=(-1.0, 1.0), work=False)
+    assert np.all(st0 == 0)
+    err0 = orc.rel_l2_coef(W0[sel], tr).max()
+    print("near-square M=%d n=%d h=%g: refined %.1e, single kernel %.1e" % (M, n, h, err, err0))
+    assert err0 >= plain_floor, err0
+    # tabulated right-hand side takes the same path
+    import torch
+    from hybrid_fem_lssvr_amd import ops
+    x = _t(nodes, dev)
+    f = _t(orc.poisson_rhs(ops.colloc_points(x, n).cpu().numpy()), dev)
+    W2, _ = ops.enhance(x, _t(values, dev), M, 1e4, n, global_domain=(-1.0, 1.0), rhs_values=f)
+    torch.cuda.synchronize()
+    assert orc.rel_l2_coef(W2.cpu().numpy()[sel], tr).max() <= 5 * bar
+
+
+def test_refinement_leaves_well_posed_sizes_alone(dev):
+    """n - (M-2) > 14 (every BASELINE configuration): no refinement kernels, 96-double workspace."""
+    from hybrid_fem_lssvr_amd import _capi
+    lib = _capi.load()
+    assert lib.lssvr_enhance_work_bytes(1000, 33, 64, 0) == 1000 * 96 * 8
+    assert lib.lssvr_enhance_work_bytes(1000, 33, 46, 0) == 1000 * 96 * 8
+    assert lib.lssvr_enhance_work_bytes(1000, 33, 45, 0) == 1000 * 128 * 8
+    assert lib.lssvr_enhance_work_bytes(1000, 22, 20, 0) == 0
