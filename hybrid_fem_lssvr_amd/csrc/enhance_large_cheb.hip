@@ -539,7 +539,7 @@ __global__ __launch_bounds__(64, 2) void enhance_large_cheb_kernel(EnhanceArgs p
 // (lssvr_enhance_ws): 242 us at 1e5 elements and 2.04 ms at 1e6 (M = 33, 64 points) against
 // 352-395 us and 3.2 ms of enhance_large_kernel.
 // =============================================================================================
-constexpr int kWsStride = 96;            // per element: m_0..m_60 at [0, 61), r_0..r_30 at [64, 95)
+constexpr int kWsStride = kMomentWsStride; // per element: m_0..m_60 at [0, 61), r_0..r_30 at [64, 95)
 
 // Phase 1 alone, ONE ELEMENT PER LANE (no slices, no reduction): 91 accumulators, all points.
 template <int RHS>
@@ -825,6 +825,7 @@ hipError_t enhance_large_split(const EnhanceArgs& a, void* work, hipStream_t s, 
   hipError_t e = sine ? go(moments_kernel<LSSVR_RHS_SIN>, g1, t1, ev0, nullptr, a, ws)
                       : go(moments_kernel<LSSVR_RHS_ARRAY>, g1, t1, ev0, nullptr, a, ws);
   if (e != hipSuccess) return e;
+  if (steps == 0 && enhance_parity_applies(a.M, a.n)) return launch_solve4_parity(a, cws, s, ev1);
   if (steps == 0) return go(solve4_kernel<0>, g2, t2, nullptr, ev1, a, cws, (double*)nullptr, nxcd);
   EnhanceArgs quiet = a;           // failures are counted once, by the last pass
   quiet.fail_count = nullptr;

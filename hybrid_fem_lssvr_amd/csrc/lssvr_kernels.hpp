@@ -73,6 +73,21 @@ inline unsigned xcd_count() {
   return cached;
 }
 
+// compute units of the current device (256 on MI355X), cached like xcd_count(); sizes persistent grids
+inline unsigned cu_count() {
+  static thread_local int cached_dev = -1;
+  static thread_local unsigned cached = 1;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 1;
+  if (dev != cached_dev) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) v = 1;
+    cached = (unsigned)v;
+    cached_dev = dev;
+  }
+  return cached;
+}
+
 hipError_t enhance_small(const EnhanceArgs& a, hipStream_t s, const LaunchOpts* o = nullptr);
 hipError_t enhance_large(const EnhanceArgs& a, hipStream_t s, const LaunchOpts* o = nullptr);
 // Poisson rows, any M <= 33: Chebyshev-moment Gram, 16 elements per wave (enhance_large_cheb.hip)
@@ -81,6 +96,10 @@ hipError_t enhance_large_cheb(const EnhanceArgs& a, hipStream_t s, const LaunchO
 int enhance_refine_steps(int M, int n);
 int64_t enhance_moment_ws_bytes(int64_t ne, int M, int n);
 hipError_t enhance_large_split(const EnhanceArgs& a, void* work, hipStream_t s, const LaunchOpts* o = nullptr);
+// the well-posed regime (n >= 2 (M-2)) of the two-kernel path: parity-split solve (enhance_large_parity.hip)
+constexpr int kMomentWsStride = 96;   // workspace doubles per element: m_0..m_60, a, b, g_l, r_0..r_30, g_r
+bool enhance_parity_applies(int M, int n);
+hipError_t launch_solve4_parity(const EnhanceArgs& a, const double* ws, hipStream_t s, hipEvent_t ev_stop);
 hipError_t enhance_dual(const EnhanceArgs& a, hipStream_t s, const LaunchOpts* o = nullptr);
 constexpr int kSharedMaxM = 33;  // shared-operator path (uniform meshes): coefficients in VGPRs
 hipError_t enhance_shared(const EnhanceArgs& a, const double* op, hipStream_t s,

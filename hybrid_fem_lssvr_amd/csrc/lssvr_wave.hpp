@@ -330,3 +330,116 @@ __device__ __forceinline__ void ldlt_solve_dpp4(double (&A)[kLP], double (&B)[kL
 
 }  // namespace wave
 }  // namespace lssvr
+
+namespace lssvr {
+namespace wave {
+
+// ---------------------------------------------------------------------------
+// PARITY-SPLIT factorisation, four systems per wave (enhance_large_parity.hip): the S matrix of an
+// element whose collocation points are symmetric about its centre is block diagonal in the
+// even / odd Chebyshev indices up to rounding-level coupling, so the 31 x 31 LDL^T becomes a
+// 16 x 16 and a 15 x 15 one in lock step: lane q of a 16-lane DPP row holds column q of the even
+// block in A and column q of the odd block in B (rows in registers), the rhs entry of its
+// columns in A[16] / B[16]:  136 + 120 broadcast-FMAs for four systems instead of 872.
+//
+//   step j:  t = A[j] (row j across the lanes; lane j: the pivot d_j);  nt_c = -a_jc / d_j (0 for
+//            c <= j);  y_c += y_j nt_c;  a_ic += a_ji nt_c  (v_fmac_f64_dpp row_newbcast:i);  then
+//            A[j] := nt in lanes c >= j -- the pivot row's upper part is dead, the multipliers
+//            -L_cj take its place (row form, for further right-hand sides).  Afterwards register
+//            A[i] holds, in lane c:  c < i: a_ic = d_c L_ic (column form, for the back-substitution),
+//            c = i: 0,  c > i: -L_ci (row form, for forward substitutions) -- the whole factor in
+//            the registers of the matrix; the substitutions mask the half they do not want.
+// Rows and columns beyond the block sizes may hold ANY finite values: steps stop at ns, a lane
+// c >= ns is never a broadcast source of anything a real lane keeps, rows >= ns feed nothing.
+// The DPP hazard rule of ldlt_solve_dpp4 applies (s_nop 1 after every DPP source is produced;
+// scripts/check_dpp_hazard.py proves it on the ISA).
+// ---------------------------------------------------------------------------
+constexpr int kPB = 16;                 // rows / columns of a parity block (padded)
+
+__device__ __forceinline__ void ldlt_parity_factor(double (&A)[kPB + 1], double (&B)[kPB + 1],
+                                                   int q, int nsteps, double& nrA, double& nrB) {
+  int qq = q;
+  asm volatile("" : "+v"(qq));
+  int ns = nsteps;
+  asm volatile("" : "+s"(ns));
+  nrA = -1.0;
+  nrB = -1.0;                      // -1/d of this lane's own pivots, latched at their step
+  static_for<0, kPB>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    if (j < ns) {
+      double tA = A[j], tB = B[j];
+      double rA = -rcp_newton(tA), rB = -rcp_newton(tB);      // lane j: -1/d_j
+      if (qq == j) {
+        nrA = rA;
+        nrB = rB;
+      }
+      asm volatile("s_nop 1" : "+v"(tA), "+v"(tB), "+v"(rA), "+v"(rB), "+v"(A[kPB]), "+v"(B[kPB]));
+      double ntA = 0.0, ntB = 0.0;
+      fmac_rowbcast<j>(ntA, rA, tA);
+      fmac_rowbcast<j>(ntB, rB, tB);
+      if (!(qq > j)) {                                        // frozen columns stay as they are
+        ntA = 0.0;
+        ntB = 0.0;
+      }
+      asm volatile("s_nop 0" : "+v"(ntA), "+v"(ntB));
+      fmac_rowbcast<j>(A[kPB], A[kPB], ntA);                  // forward substitution rides along
+      fmac_rowbcast<j>(B[kPB], B[kPB], ntB);
+      static_for<j + 1, kPB>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        fmac_rowbcast<i>(A[i], tA, ntA);
+        fmac_rowbcast<i>(B[i], tB, ntB);
+      });
+      if (qq >= j) {
+        A[j] = ntA;
+        B[j] = ntB;
+      }
+    }
+  });
+}
+
+// L y = r for a further right-hand side (one entry per lane and block), in place.
+__device__ __forceinline__ void ldlt_parity_forward(const double (&A)[kPB + 1], const double (&B)[kPB + 1],
+                                                    int q, int nsteps, double& yA, double& yB) {
+  int qq = q;
+  asm volatile("" : "+v"(qq));
+  int ns = nsteps;
+  asm volatile("" : "+s"(ns));
+  static_for<0, kPB - 1>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    if (j < ns) {
+      asm volatile("s_nop 1" : "+v"(yA), "+v"(yB));
+      // lanes c >= j only (EXEC mask instead of zeroed multipliers: the source lane j stays active
+      // and its own entry A[j] is 0)
+      if (qq >= j) {
+        fmac_rowbcast<j>(yA, yA, A[j]);                       // y_c -= L_cj y_j
+        fmac_rowbcast<j>(yB, yB, B[j]);
+      }
+    }
+  });
+}
+
+// L^T z = D^-1 y out of the column-form entries; y in, z out.
+__device__ __forceinline__ void ldlt_parity_backward(const double (&A)[kPB + 1], const double (&B)[kPB + 1],
+                                                     int q, int nsteps, double nrA, double nrB,
+                                                     double& yA, double& yB) {
+  int qq = q;
+  asm volatile("" : "+v"(qq));
+  int ns = nsteps;
+  asm volatile("" : "+s"(ns));
+  static_for<1, kPB>([&](auto ir) {
+    constexpr int i = kPB - decltype(ir)::value;              // i = 15 .. 1
+    if (i < ns) {
+      double nzA = yA * nrA, nzB = yB * nrB;                  // lane i: -z_i
+      asm volatile("s_nop 1" : "+v"(nzA), "+v"(nzB));
+      if (qq <= i) {                                          // columns t <= i (lane i: A[i] = 0)
+        fmac_rowbcast<i>(yA, nzA, A[i]);                      // Y_t -= a_it z_i
+        fmac_rowbcast<i>(yB, nzB, B[i]);
+      }
+    }
+  });
+  yA = -(yA * nrA);
+  yB = -(yB * nrB);
+}
+
+}  // namespace wave
+}  // namespace lssvr
