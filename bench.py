@@ -761,11 +761,15 @@ def run_single(args, D, M, n, ne_glob, lo, hi, dev, cpu_res, use_dist):
                 "gfx950 are the same 78.6 TFLOP/s and share one pipe (DESIGN.md section 3)")
         solver_lbl = "primal, BC-eliminated SPD (M-2), Chebyshev-moment Gram, LDL^T"
     else:
-        kernel_name, bound = "moments_kernel + solve4_kernel (the pair, gap included)", "fp64-valu"
-        pipe = ("FP64 vector pipe: Chebyshev moments (lane per element) + four-systems-per-wave DPP-broadcast LDL^T; "
-                "the f64-MFMA Gram kernel (LSSVR_SOLVER_PRIMAL_WAVE) is 1.4-1.5x slower (DESIGN.md section 3.8); "
-                "vector and matrix FP64 share one pipe at the same 78.6 TFLOP/s peak")
-        solver_lbl = "primal, BC-eliminated SPD (M-2), Chebyshev-moment Gram, LDL^T (two kernels, workspace)"
+        second = "solve4_parity_kernel" if n >= 2 * (M - 2) else "solve4_kernel (+ refinement kernels when n <= M + 12)"
+        kernel_name, bound = "moments_kernel + %s (the sequence, gaps included)" % second, "fp64-valu"
+        pipe = ("FP64 vector pipe: Chebyshev moments (lane per element) + parity-split four-systems-per-wave "
+                "DPP-broadcast LDL^T (persistent waves); it executes about a quarter of the flops the formula "
+                "prices, so frac can exceed what a direct Gram could reach; the f64-MFMA Gram kernel "
+                "(LSSVR_SOLVER_PRIMAL_WAVE) is 2x slower (DESIGN.md section 3.8); vector and matrix FP64 share one "
+                "pipe at the same 78.6 TFLOP/s peak")
+        solver_lbl = ("primal, BC-eliminated SPD (M-2), Chebyshev-moment Gram, parity-split LDL^T + coupling "
+                      "iteration (two kernels, workspace)")
     out = {
         "metric": "LSSVR-enhanced elements/sec, 1D Poisson deg-%d/%d-pt" % (args.degree, n),
         "value": total / elapsed,

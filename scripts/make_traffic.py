@@ -41,7 +41,7 @@ res = {"_how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes
 small = kernel_bytes(prof + "/fetch", prof + "/write", "enhance_small_kernel")
 cal = {"fetch": small["fetch"][1], "write": small["write"][1]}
 res["_calibration_bytes_per_counted_byte"] = cal
-large = kernel_bytes(prof + "/fetchL", prof + "/writeL", ("moments_kernel", "solve4_kernel"), probe=cal)
+large = kernel_bytes(prof + "/fetchL", prof + "/writeL", ("moments_kernel", "solve4_parity_kernel"), probe=cal)
 mfma = kernel_bytes(prof + "/fetchLm", prof + "/writeLm", "enhance_large_kernel", probe=cal)
 shared = kernel_bytes(prof + "/fetchS", prof + "/writeS", "enhance_shared_kernel", probe=cal)
 for key, kb, alg in (("M9_n16_ne100008", small, 88 * 100008), ("M33_n64_ne100000", large, 280 * 100000),

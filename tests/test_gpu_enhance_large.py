@@ -255,3 +255,70 @@ def test_refinement_leaves_well_posed_sizes_alone(dev):
     assert lib.lssvr_enhance_work_bytes(1000, 33, 46, 0) == 1000 * 96 * 8
     assert lib.lssvr_enhance_work_bytes(1000, 33, 45, 0) == 1000 * 128 * 8
     assert lib.lssvr_enhance_work_bytes(1000, 22, 20, 0) == 0
+
+
+# (M, n, x0, h, ne): the parity-split solve kernel (csrc/enhance_large_parity.hip) over its regimes:
+# both parities of the number of bubble coefficients (padding column of the odd block), every tail of
+# the four-element rounds, point sets from exactly symmetric to strongly asymmetric in float64
+# (contraction rate of the coupling iteration 1e-13 ... 4e-4: one to several corrections), and
+# elements beyond the first-order range of the boundary rows (cold exact path inside the kernel).
+PARITY_CASES = [
+    (33, 64, -1.0, 1.0 / 12, 24),
+    (33, 64, -4166.0, 1.0 / 12, 37),        # rho = 3e-6: block solve alone is 5e-12 off
+    (33, 64, 416666.0, 1.0 / 12, 5),
+    (33, 64, 0.9999, 2.0e-7, 9),            # |x|/h = 5e6: rho = 4e-4, several corrections
+    (33, 62, -0.7, 0.03, 3),                # n = 2 (M-2) exactly: the gate of the kernel
+    (32, 60, -4166.0, 1.0 / 12, 2),         # 30 bubble coefficients: 15 + 15
+    (31, 64, 12.5, 0.125, 1),               # 29: 15 + 14
+    (24, 44, -4166.0, 1.0 / 12, 6),         # 22: 11 + 11
+    (23, 42, 3.0, 0.01, 7),                 # 21: 11 + 10
+    (33, 96, 1.0e8, 1.0, 6),                # |x|/h = 1e8: boundary rows by the exact recurrence
+    (27, 80, -3.0e7, 0.5, 4),
+]
+
+
+@pytest.mark.parametrize("M,n,x0,h,ne", PARITY_CASES)
+def test_parity_split_regimes(dev, M, n, x0, h, ne):
+    import torch
+    from hybrid_fem_lssvr_amd import ops
+    assert n >= 2 * (M - 2) and M > 22                      # (the regime the kernel is launched for)
+    rng = np.random.default_rng(int(M * 1000 + n + ne))
+    nodes = x0 + h * np.arange(ne + 1)
+    values = np.sin(np.pi * nodes) + 0.01 * rng.standard_normal(ne + 1)
+    gd = (nodes[0], nodes[-1])
+    W, st = _enhance(dev, nodes, values, M, 1e4, n, global_domain=gd)
+    assert np.all(st == 0)
+    W1, st1 = _enhance(dev, nodes, values, M, 1e4, n, global_domain=gd, work=False)   # single f64-MFMA kernel
+    assert np.all(st1 == 0)
+    assert orc.rel_l2_coef(W, W1).max() <= 1e-12
+    if cf.HAVE_MP:
+        sel = sorted({0, ne // 2, ne - 1})
+        tr = cf.truth_all(nodes, values, M, 1e4, n, orc.poisson_rhs, gd, sel)
+        err = orc.rel_l2_coef(W[sel], tr).max()
+        assert err <= TOL_TRUTH, err
+    # tabulated right-hand side: same kernels, same answer
+    x = _t(nodes, dev)
+    f = _t(orc.poisson_rhs(ops.colloc_points(x, n).cpu().numpy()), dev)
+    W2, _ = ops.enhance(x, _t(values, dev), M, 1e4, n, global_domain=gd, rhs_values=f)
+    torch.cuda.synchronize()
+    assert orc.rel_l2_coef(W2.cpu().numpy(), W).max() <= 1e-12
+
+
+def test_parity_split_per_element_gamma_and_failures(dev):
+    """gamma_values / fail_count / status through the persistent parity kernel: a degenerate element
+    (zero length) and a NaN nodal value fall back, everything else matches the oracle."""
+    import torch
+    from hybrid_fem_lssvr_amd import ops
+    ne, M, n = 43, 33, 64
+    nodes = np.linspace(0.0, 1.0, ne + 1)
+    nodes[11] = nodes[10]
+    values = np.sin(nodes)
+    values[30] = np.nan
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    W, st = ops.enhance(_t(nodes, dev), _t(values, dev), M, 1e4, n, fail_count=cnt, global_domain=(0.0, 1.0))
+    torch.cuda.synchronize()
+    st = st.cpu().numpy()
+    assert set(np.nonzero(st)[0]) == {10, 29, 30} and int(cnt.item()) == 3
+    good = [0, 5, 20, 42]
+    Wo = orc.enhance_all_vec(nodes, np.nan_to_num(values), M, 1e4, n, global_domain=(0.0, 1.0))
+    assert orc.rel_l2_coef(W.cpu().numpy()[good], Wo[good]).max() <= 1e-11
