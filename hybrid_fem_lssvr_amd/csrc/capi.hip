@@ -97,7 +97,7 @@ int enhance_dispatch(const lssvr::EnhanceArgs& a, int solver_id, hipStream_t s,
   if (a.elem_ids && solver_id != LSSVR_SOLVER_PRIMAL)
     return fail(LSSVR_ERR_SOLVER, "subset launches take LSSVR_SOLVER_PRIMAL");
   // large degree, Poisson rows, workspace given: Chebyshev moments + four-systems-per-wave solve as
-  // two kernels (1.4-1.5x the speed of the MFMA kernel)
+  // two kernels (twice the speed of the MFMA kernel)
   if (solver_id == LSSVR_SOLVER_PRIMAL && !a.a_values && !a.elem_ids && work &&
       work_bytes >= lssvr::enhance_moment_ws_bytes(a.ne, a.M, a.n))
     return check_launch(lssvr::enhance_large_split(a, work, s, o), "enhance_large_split");

@@ -32,8 +32,10 @@
 // against 352-395 us and 3.2 ms of enhance_large.hip -- the 91 accumulators of phase 1 and the 128
 // column registers of phase 2 leave 2 resident waves per SIMD and make the waves long.  The SAME
 // two phases as two kernels with a workspace in between (moments_kernel + solve4_kernel, bottom of
-// this file) take 242 us and 2.04 ms and are what LSSVR_SOLVER_PRIMAL runs above M = 22; the
-// fused kernel stays reachable as LSSVR_SOLVER_PRIMAL_MOMENT without a workspace.
+// this file) take 242 us and 2.04 ms; with the parity-split solve of enhance_large_parity.hip in
+// place of solve4_kernel (n >= 2 (M-2)) 195 us and 1.5 ms -- that sequence is what
+// LSSVR_SOLVER_PRIMAL runs above M = 22; the fused kernel stays reachable as
+// LSSVR_SOLVER_PRIMAL_MOMENT without a workspace.
 #include "cheb_tables.hpp"
 #include "lssvr_device.hpp"
 #include "lssvr_kernels.hpp"
@@ -537,7 +539,8 @@ __global__ __launch_bounds__(64, 2) void enhance_large_cheb_kernel(EnhanceArgs p
 // elements each) and the tables sit in LDS -- what the fused kernel above lacks.
 // This pair is the DEFAULT for Poisson rows above M = 22 whenever the caller passes a workspace
 // (lssvr_enhance_ws): 242 us at 1e5 elements and 2.04 ms at 1e6 (M = 33, 64 points) against
-// 352-395 us and 3.2 ms of enhance_large_kernel.
+// 352-395 us and 3.2 ms of enhance_large_kernel; where n >= 2 (M-2) the second kernel is the
+// parity-split solve4_parity_kernel of enhance_large_parity.hip instead (195 us / 1.5 ms).
 // =============================================================================================
 constexpr int kWsStride = kMomentWsStride; // per element: m_0..m_60 at [0, 61), r_0..r_30 at [64, 95)
 

@@ -118,7 +118,7 @@ int lssvr_enhance(const double* x, const double* u, int64_t ne,
  * lssvr_enhance_ws -- lssvr_enhance with a caller-provided device workspace (the library still
  * allocates nothing).  Poisson rows above M = 22 then run as TWO kernels -- Chebyshev moments of
  * the collocation points (96 doubles per element into `work`), then the four-systems-per-wave
- * solve -- 1.5x the speed of the single f64-MFMA kernel lssvr_enhance launches without a
+ * solve -- twice the speed of the single f64-MFMA kernel lssvr_enhance launches without a
  * workspace.  Where n_colloc - (M-2) <= 14 (about as many equispaced
  * points as bubble coefficients: normal equations lose up to ten digits) the pair is followed by
  * 1-3 refinement steps with the residual taken through the collocation rows (32 more doubles per
