@@ -7,10 +7,11 @@ from oracle import lssvr_oracle as orc, closed_form_mp as cf
 
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 solver = int(sys.argv[3]) if len(sys.argv) > 3 else ops.SOLVER_PRIMAL      # 2 = force the wave / MFMA mapping
+m_lo = int(sys.argv[4]) if len(sys.argv) > 4 else 2                        # e.g. 23: large-degree kernels only
 dev = torch.device("cuda:0")
 worst = []
 for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 120):
-    M = int(rng.integers(2, 34))
+    M = int(rng.integers(m_lo, 34))
     n = int(rng.integers(2, 81))
     gamma = 10.0 ** rng.uniform(-2, 8)
     h = 10.0 ** rng.uniform(-7, 1)
@@ -32,7 +33,14 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 120):
     sel = [0, 5, 11]
     tr = cf.truth_all(nodes, values, M, gamma, n, orc.poisson_rhs, gd, sel)
     err = orc.rel_l2_coef(W[sel], tr)
-    route = "dual" if n < M - 2 else ("lane" if (M <= 22 and solver == ops.SOLVER_PRIMAL) else "wave")
+    if n < M - 2:
+        route = "dual"
+    elif M <= 22 and solver == ops.SOLVER_PRIMAL:
+        route = "lane"
+    elif solver != ops.SOLVER_PRIMAL:
+        route = "mfma"
+    else:
+        route = "parity" if n >= 2 * (M - 2) else ("refined" if n - (M - 2) <= 14 else "solve4")
     e = float(np.nanmax(err)) if np.all(st[sel] == 0) else float("nan")
     worst.append((e, M, n, gamma, h, x0, route, int(st.sum())))
 worst.sort(key=lambda t: (-(t[0] if t[0] == t[0] else 1e9)))
