@@ -386,10 +386,14 @@ __global__ __launch_bounds__(64) void enhance_dual_kernel(EnhanceArgs p, int nre
     const double res_c = residual(lam_c, wv_c, nrm_c);
     const bool better = nrm_c < 4.0 * nrm;       // (NaN: rejected; a step may raise the norm 2x: at the
                                                  // rounding floor the norm is noise, a diverging step gains 100x)
+    // a rejected step would be recomputed identically, a step that gains less than 2x in the norm
+    // is at the rounding floor: the wave stops refining once none of its elements gains any more
+    const bool gains = better && (nrm_c < 0.25 * nrm);
     lam = better ? lam_c : lam;
     wv = better ? wv_c : wv;
     res = better ? res_c : res;
     nrm = better ? nrm_c : nrm;
+    if (!__any(gains)) break;
   }
   // ---- w = w_bc + w', re-projected onto the boundary rows -------------------------------------
   double wp = 0.0;
