@@ -219,7 +219,8 @@ __device__ __forceinline__ void enhance_small_body_cheb(const EnhanceArgs& p, co
           rc *= kappa;
         }
         const int k1 = min(k0 + kReseed, n);
-        for (int k = k0; k < k1; ++k) {
+        // one collocation point: abscissa xk (np.linspace), index k of the element, k0 of the chunk
+        auto point = [&](const double xk, const int k) {
           if constexpr (RHS == LSSVR_RHS_ARRAY) {
             if ((k & (kStageK - 1)) == 0) {
               __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -236,19 +237,21 @@ __device__ __forceinline__ void enhance_small_body_cheb(const EnhanceArgs& p, co
               __builtin_amdgcn_wave_barrier();
             }
           }
-          // np.linspace / mapdomain, two roundings each (step == 0 needs h < 1e-320, where
-          // scl = 2/h overflows and the element ends in the linear fallback whatever x_k is)
-          const double xk = (k == n - 1) ? b : (double)k * step + a;
-          const double tk = dm.off + dm.scl * xk;
+          const double tk = dm.off + dm.scl * xk;         // mapdomain, two roundings
           double phi2;
           if constexpr (RHS == LSSVR_RHS_SIN) {
             const double arg = p.rhs_omega * xk;
             const double delta = fma(-(double)(k - k0), dth, arg - th0);
             phi2 = fma(rc, delta, rs);
             if (__any(!(fabs(delta) < 1.0e-7))) phi2 = kappa * sin_tab(arg, p.trig);
-            const double rs_next = fma(rs, cd, rc * sd);
-            rc = fma(rc, cd, -(rs * sd));
+            // the rotation, written as three-operand FMAs into the carried registers themselves
+            // (hipcc picks v_fmac + a copy per loop-carried value otherwise: 2 of 45 instructions)
+            const double t1 = rc * sd, t2 = rs * sd;
+            double rs_next, rc_next;
+            asm("v_fma_f64 %0, %1, %2, %3" : "=v"(rs_next) : "v"(rs), "v"(cd), "v"(t1));
+            asm("v_fma_f64 %0, %1, %2, -%3" : "=v"(rc_next) : "v"(rc), "v"(cd), "v"(t2));
             rs = rs_next;
+            rc = rc_next;
           } else {
             phi2 = stg[lane * (kStageK + 1) + (k & (kStageK - 1))] * fscale;
           }
@@ -266,7 +269,13 @@ __device__ __forceinline__ void enhance_small_body_cheb(const EnhanceArgs& p, co
             P[d] = fma(T[MR - 1], T[d], P[d]);
             rv[d] = fma(T[d], phi2, rv[d]);
           }
-        }
+        };
+        // np.linspace: fl(fl(k step) + a) for k < n-1, the last sample is b itself (step == 0 needs
+        // h < 1e-320, where scl = 2/h overflows and the element ends in the linear fallback whatever
+        // x_k is); the last point is peeled so that the loop carries no select
+        const int kl = min(k1, n - 1);
+        for (int k = k0; k < kl; ++k) point((double)k * step + a, k);
+        if (k1 == n) point(b, n - 1);
       }
       mom[0] = (double)n;
       // all moments m_0 .. m_{2MR-2}:  m_{MR-1+j} = 2 P_j - m_{MR-1-j}
