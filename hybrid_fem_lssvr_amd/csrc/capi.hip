@@ -101,14 +101,16 @@ int enhance_dispatch(const lssvr::EnhanceArgs& a, int solver_id, hipStream_t s,
   if (solver_id == LSSVR_SOLVER_PRIMAL && !a.a_values && !a.elem_ids && work &&
       work_bytes >= lssvr::enhance_moment_ws_bytes(a.ne, a.M, a.n))
     return check_launch(lssvr::enhance_large_split(a, work, s, o), "enhance_large_split");
-  // otherwise the direct Gram on the f64 matrix cores; LSSVR_SOLVER_PRIMAL_MOMENT forces the moment
-  // form (fused single kernel without a workspace: 2 resident waves per SIMD, slower)
+  // LSSVR_SOLVER_PRIMAL_MOMENT forces that sequence for any M (A/B against the lane kernel below M = 23)
   if (solver_id == LSSVR_SOLVER_PRIMAL_MOMENT) {
     if (a.a_values) return fail(LSSVR_ERR_SOLVER, "LSSVR_SOLVER_PRIMAL_MOMENT: Poisson rows only");
-    if (work && work_bytes >= lssvr::enhance_moment_ws_bytes(a.ne, a.M, a.n) && !a.elem_ids)
-      return check_launch(lssvr::enhance_large_split(a, work, s, o), "enhance_large_split");
-    return check_launch(lssvr::enhance_large_cheb(a, s, o), "enhance_large_cheb");
+    if (a.elem_ids) return fail(LSSVR_ERR_SOLVER, "LSSVR_SOLVER_PRIMAL_MOMENT: no subset form");
+    if (!work || work_bytes < lssvr::enhance_moment_ws_bytes(a.ne, a.M, a.n))
+      return fail(LSSVR_ERR_SOLVER, "LSSVR_SOLVER_PRIMAL_MOMENT needs a workspace of "
+                  "lssvr_enhance_work_bytes() bytes (lssvr_enhance_ws)");
+    return check_launch(lssvr::enhance_large_split(a, work, s, o), "enhance_large_split");
   }
+  // otherwise the direct Gram on the f64 matrix cores
   return check_launch(lssvr::enhance_large(a, s, o), "enhance_large");
 }
 }  // namespace
@@ -140,8 +142,9 @@ int lssvr_enhance(const double* x, const double* u, int64_t ne, int64_t elem_off
 }
 
 int64_t lssvr_enhance_work_bytes(int64_t ne, int M, int n_colloc, int solver_id) {
-  if (ne <= 0 || M <= lssvr::kSmallMaxM) return 0;
-  if (solver_id != LSSVR_SOLVER_PRIMAL && solver_id != LSSVR_SOLVER_PRIMAL_MOMENT) return 0;
+  if (ne <= 0) return 0;
+  if (solver_id == LSSVR_SOLVER_PRIMAL_MOMENT) return lssvr::enhance_moment_ws_bytes(ne, M, n_colloc);
+  if (solver_id != LSSVR_SOLVER_PRIMAL || M <= lssvr::kSmallMaxM) return 0;
   return lssvr::enhance_moment_ws_bytes(ne, M, n_colloc);
 }
 

@@ -1,41 +1,37 @@
 // Per-element LSSVR enhancement, large-degree path for POISSON rows (23 <= M <= 33; any M >= 2 on
 // request): the Chebyshev-moment form of the Legendre Gram contraction (DESIGN.md section 2b,
-// enhance_small_cheb.hpp) in a two-phase wave mapping.
+// enhance_small_cheb.hpp) as a SEQUENCE of kernels with a caller-provided workspace in between.
 //
 //   G_ik = sum_k' T_i(t_k') T_k(t_k') = 1/2 (m_{i+k} + m_{|i-k|}),   m_d = sum_k' T_d(t_k'), d <= 60:
 // the 31 x 31 Gram matrix of a degree-32 element is determined by 61 power sums -- O(n M) work per
 // element instead of the O(n M^2) of the direct contraction (which enhance_large.hip runs on the f64
-// matrix cores and which stays in the library for variable-coefficient rows and as
-// LSSVR_SOLVER_PRIMAL_WAVE, the A/B reference: DESIGN.md section 7).
+// matrix cores and which stays in the library for variable-coefficient rows, subsets, callers
+// without a workspace and as LSSVR_SOLVER_PRIMAL_WAVE, the A/B reference: DESIGN.md section 7).
 //
-// One wave works on 16 consecutive elements.
-//   Phase 1 (moments): lane = (element i1 = lane >> 2, point slice s = lane & 3).  The lane walks the
-//     collocation points k = s, s+4, ... of its element: abscissa and t_k in numpy's arithmetic,
-//     f(x_k) by the rotation-carried (sin, cos) pair with numpy's argument rounding restored to first
-//     order (enhance_small_cheb.hpp), T_0..T_30 by the two-term recurrence with two registers of
-//     state, and accumulates m_1..m_30 (adds), the squares T_j^2 (j = 16..30) and neighbour products
-//     T_j T_{j+1} (j = 15..29) that give the upper moments (T_j^2 = (T_2j + T_0)/2, T_j T_{j+1} =
-//     (T_{2j+1} + T_1)/2), and the right-hand side r_i = sum T_i phi: 91 accumulators, ~135
-//     instructions per point, no cross-lane traffic in the loop.  Two xor-shuffles combine the four
-//     slices; the 92 numbers per element go to LDS.  The phase is the same for every M (degree 30
-//     always: the padding costs nothing that the old 32-column padding did not).
-//   Phase 2 (solve), rounds of FOUR elements: lane (g = lane >> 4, q = lane & 15) builds columns q
-//     and q + 16 of  S2 = m_{i+c} + m_{|i-c|} + 2 eps (N + C_z^T C_z)  straight from the moments
-//     (two conflict-free LDS reads, one table load and four FMAs per entry; first-order boundary
-//     rows and compile-time ridge tables as in the lane kernel), the right-hand side rides along
-//     as row / column 31, then the four-systems-per-wave DPP-broadcast LDL^T of lssvr_wave.hpp
-//     (16 lanes per system, two columns per lane, factor frozen in registers, no LDS, no
-//     cross-row permutes), DPP back-substitution, v = Y z through LDS, w_{0,1} by row reductions.
-// No MFMA, no operand staging, no accumulator transposition -- and half the instructions of
-// enhance_large.hip (880 against 980 vector + 160 matrix instructions per element).  MEASURED
-// (MI355X, M = 33, 64 points): this FUSED kernel 407-490 us at 1e5 elements and 3.3-3.9 ms at 1e6
-// against 352-395 us and 3.2 ms of enhance_large.hip -- the 91 accumulators of phase 1 and the 128
-// column registers of phase 2 leave 2 resident waves per SIMD and make the waves long.  The SAME
-// two phases as two kernels with a workspace in between (moments_kernel + solve4_kernel, bottom of
-// this file) take 242 us and 2.04 ms; with the parity-split solve of enhance_large_parity.hip in
-// place of solve4_kernel (n >= 2 (M-2)) 195 us and 1.5 ms -- that sequence is what
-// LSSVR_SOLVER_PRIMAL runs above M = 22; the fused kernel stays reachable as
-// LSSVR_SOLVER_PRIMAL_MOMENT without a workspace.
+//   moments_kernel: ONE ELEMENT PER LANE.  The lane walks the collocation points of its element:
+//     abscissa and t_k in numpy's arithmetic, f(x_k) by the rotation-carried (sin, cos) pair with
+//     numpy's argument rounding restored to first order (enhance_small_cheb.hpp), T_0..T_30 by the
+//     two-term recurrence with two registers of state, and accumulates m_1..m_30 (adds), the squares
+//     T_j^2 (j = 16..30) and neighbour products T_j T_{j+1} (j = 15..29) that give the upper moments
+//     (T_j^2 = (T_2j + T_0)/2, T_j T_{j+1} = (T_{2j+1} + T_1)/2), and the right-hand side
+//     r_i = sum T_i phi: 91 accumulators, ~135 instructions per point, no cross-lane traffic.  The
+//     96 numbers per element (moments, end points, boundary values, r) go to the workspace.  The
+//     kernel is the same for every M (degree 30 always).
+//   solve: n >= 2 (M-2): solve4_parity_kernel of enhance_large_parity.hip (even / odd split);
+//     otherwise solve4_kernel below, rounds of FOUR elements per wave: lane (g = lane >> 4,
+//     q = lane & 15) builds columns q and q + 16 of  S2 = m_{i+c} + m_{|i-c|} + 2 eps (N + C_z^T C_z)
+//     straight from the moments (two conflict-free LDS reads, one table read and four FMAs per
+//     entry; first-order boundary rows and compile-time ridge tables as in the lane kernel), the
+//     right-hand side rides along as row / column 31, then the four-systems-per-wave DPP-broadcast
+//     LDL^T of lssvr_wave.hpp (16 lanes per system, two columns per lane, factor frozen in
+//     registers, no LDS, no cross-row permutes), DPP back-substitution, v = Y z through LDS,
+//     w_{0,1} by row reductions; n <= M + 12: followed by refinement steps (residual_kernel +
+//     solve4_kernel<2>).
+// MEASURED (MI355X, M = 33, 64 points): 242 us at 1e5 elements and 2.04 ms at 1e6 with solve4_kernel,
+// 195 us and 1.5 ms with the parity-split solve, against 352-395 us and 3.2 ms of enhance_large.hip.
+// (A fused single-kernel form of the two phases -- sixteen elements per wave, moments through LDS
+// atomics -- took 407-490 us / 3.3-3.9 ms: 91 accumulators plus 128 column registers leave two
+// long-lived waves per SIMD.  It was removed; DESIGN.md section 3.8 keeps its numbers.)
 #include "cheb_tables.hpp"
 #include "lssvr_device.hpp"
 #include "lssvr_kernels.hpp"
@@ -47,27 +43,8 @@ using namespace wave;
 
 namespace {
 
-constexpr int kEPW = 16;                 // elements per wave (measured: 8 per wave, with three-step slice
-                                         // reductions, is 16 % slower at 1e5 elements and 30 % at 1e6)
-constexpr int kSlices = 64 / kEPW;       // phase 1: lanes (= point slices) per element
-constexpr int kSliceShift = 2;
-static_assert((1 << kSliceShift) == kSlices, "slice shift");
-constexpr int kReseedLarge = 64;         // rotation-carried rhs: re-seeded every 64 points of a slice
+constexpr int kReseedLarge = 64;         // rotation-carried rhs: re-seeded every 64 points
 constexpr int kTop = 30;                 // highest Chebyshev degree of a row (M = 33)
-// m_0 .. m_60 of an element; stride 80 doubles = 160 banks: the two 16-lane groups that share a
-// 32-lane half of a ds_read_b64 land on disjoint bank halves (stride 64 was a 2-way conflict)
-constexpr int kMomStride = 80;
-constexpr int kRStride = 48;             // r_0 .. r_30, same rule (96 banks = 32 mod 64)
-constexpr int kMomDoubles = kEPW * kMomStride;
-constexpr int kRDoubles = kEPW * kRStride;
-constexpr int kNDoubles = 0;             // (N = Y^T Y is read from the L1-resident device table)
-constexpr int kQuarterDoubles = 64;      // per 16-lane row: Z (z for v = Y z; entries [32, 64) stay 0)
-constexpr int kLdsDoubles = kMomDoubles + kRDoubles + kNDoubles + 4 * kQuarterDoubles;
-
-// LDS accumulate (ds_add_f64, no return value)
-__device__ __forceinline__ void lds_add(double* addr, double v) {
-  __hip_atomic_fetch_add(addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
 
 // sum over the 16 lanes of a DPP row
 __device__ __forceinline__ double row_sum16(double v) {
@@ -103,19 +80,18 @@ __device__ const ChebDeviceTables kTab = make_cheb_device_tables();
 
 
 // ---------------------------------------------------------------------------------------------
-// One round of phase 2: four elements (one per 16-lane DPP row), from their moments mo[0..60] and
-// right-hand sides ro[0..30] (LDS, this lane's element) to the stored coefficient row.  Lane
-// (g = lane >> 4, q = lane & 15) owns columns q and q + 16 of its element's system.
-// Z: this row's 64 doubles of LDS ([32, 64) stay zero).
+// The solve of four elements (one per 16-lane DPP row), from their moments mo[0..60], end points
+// and boundary values (mo[61..63], ro[31]) and right-hand sides ro[0..30] (LDS, this lane's
+// element) to the stored coefficient row.  Lane (g = lane >> 4, q = lane & 15) owns columns q and
+// q + 16 of its element's system.  Z: this row's 64 doubles of LDS ([32, 64) stay zero).
 // ---------------------------------------------------------------------------------------------
-// Ntab (row stride 32) / Ytab (row stride 64): the device tables or LDS copies of them.
-// PRE: the element's a, b, g_l, g_r come with the moments (mo[61..63], ro[31]; split kernels).
+// Ntab (row stride 32) / Ytab (row stride 64): LDS copies of the device tables.
 // MODE (iterative refinement of the near-square regime, refine_steps() below): 0 = plain solve;
 // 1 = also store the Chebyshev coefficients z to zout[0..32); 2 = a refinement step: ro[] holds
 // sum_k T_i(t_k) e_k of the point residual e = phi2 - 2 T zold (residual_kernel), the ridge part
 // of the residual is formed here from the ridge entries of S as they are built, the solve gives
 // the correction and z = zold + dz goes on to W and to zout.
-template <bool PRE, int MODE = 0>
+template <int MODE>
 __device__ __forceinline__ void solve_four(const EnhanceArgs& p, const int lane, const int64_t e_raw,
                                            const double* __restrict__ mo,
                                            const double* __restrict__ ro, double* __restrict__ Z,
@@ -125,7 +101,7 @@ __device__ __forceinline__ void solve_four(const EnhanceArgs& p, const int lane,
                                            double* __restrict__ zout = nullptr) {
   const int M = p.M, MR = M - 2;
   int q = lane & 15;
-  asm volatile("" : "+v"(q));      // (keeps phase 2's lane constants out of phase 1's register budget)
+  asm volatile("" : "+v"(q));
   Z[32 + q] = 0.0;
   Z[48 + q] = 0.0;
   const int cA = q, cB = q + 16;
@@ -147,19 +123,7 @@ __device__ __forceinline__ void solve_four(const EnhanceArgs& p, const int lane,
         id = 0;
       }
     }
-    double a, b, gl, gr;
-    if constexpr (PRE) {
-      a = mo[61];
-      b = mo[62];
-      gl = mo[63];
-      gr = ro[31];
-    } else {
-      a = p.x[id];
-      b = p.x[id + 1];
-      const int64_t eg = id + p.elem_offset;
-      gl = (eg == 0 && a == p.gxmin) ? p.bc_left : p.u[id];
-      gr = (eg == p.ne_global - 1 && b == p.gxmax) ? p.bc_right : p.u[id + 1];
-    }
+    const double a = mo[61], b = mo[62], gl = mo[63], gr = ro[31];
     const double inv_gamma = p.gamma_values ? rcp_newton(p.gamma_values[id]) : p.inv_gamma;
     const DomainMap dm = map_params(a, b);
     const double hh = 0.5 * dm.oldlen;
@@ -371,167 +335,6 @@ __device__ __forceinline__ void solve_four(const EnhanceArgs& p, const int lane,
   }
 }
 
-template <int RHS>
-__global__ __launch_bounds__(64, 2) void enhance_large_cheb_kernel(EnhanceArgs p, unsigned nxcd) {
-  __shared__ double2_t lds2[kLdsDoubles / 2];
-  double* const lds = reinterpret_cast<double*>(lds2);
-  double* const Mom = lds;
-  double* const Rv = lds + kMomDoubles;
-  const int lane = threadIdx.x & 63;
-  const int n = p.n;
-
-  // XCD-aware numbering: consecutive 16-element blocks go to consecutive workgroups OF ONE XCD, so
-  // the lines of x / u are fetched by one L2 (enhance_large.hip measured 2.5 MB instead of 7.2 MB)
-  const unsigned xcd = blockIdx.x % nxcd, slot = blockIdx.x / nxcd;
-  const int64_t blk = (int64_t)xcd * (gridDim.x / nxcd) + slot;
-  const int64_t E0 = blk * kEPW;
-  if (E0 >= p.ne) return;
-
-  // =========================== phase 1: moments ============================================
-  {
-    const int i1 = lane >> kSliceShift, s = lane & (kSlices - 1);
-    const int64_t e1 = (E0 + i1 < p.ne) ? E0 + i1 : p.ne - 1;     // tail: duplicates (never stored)
-    int64_t id = e1;
-    if (p.elem_ids) {
-      id = p.elem_ids[e1];
-      if (id < 0 || id >= p.ne_mesh) id = 0;                      // (reported in phase 2)
-    }
-    const double a = p.x[id];
-    const double b = p.x[id + 1];
-    const DomainMap dm = map_params(a, b);
-    const double step = dm.oldlen / (double)(n - 1);
-    const double hh = 0.5 * dm.oldlen;
-    const double inv_scl2 = hh * hh;                              // 1 / scl^2 within 2 ulp
-
-    // zero the wave's accumulation area (slices add into it with LDS atomics below)
-#pragma unroll
-    for (int t = 0; t < (kMomDoubles + kRDoubles + 63) / 64; ++t)
-      if (t * 64 + lane < kMomDoubles + kRDoubles) lds[t * 64 + lane] = 0.0;
-    wave_lds_sync();
-    double* const mo = Mom + i1 * kMomStride;
-    double* const ro = Rv + i1 * kRStride;
-
-    // Two passes over the slice's points, so that neither holds more than 61 accumulators (one pass
-    // with all 91 pushed the kernel over 256 VGPRs: 190 spilled registers, reloaded in the solve
-    // rounds -- the waves spent half their life in s_waitcnt): pass 0 = moments m_1..m_30 and the
-    // right-hand side, pass 1 = the squares / neighbour products of the upper moments.  The
-    // abscissae and the T recurrence are recomputed (29 FMAs per point, +4 % instructions).
-    double rs = 0.0, rc = 1.0, sd = 0.0, cd = 1.0, th0 = 0.0, dth4 = 0.0, kappa = 0.0;
-    if constexpr (RHS == LSSVR_RHS_SIN) {
-      dth4 = (double)kSlices * (p.rhs_omega * step);            // angle between a slice's points
-      sincos_tab(dth4, sd, cd, p.trig);
-      kappa = -2.0 * (p.rhs_amp * inv_scl2);                      // phi2 = -2 f / scl^2
-    }
-    [[maybe_unused]] const double fscale = -2.0 * inv_scl2;
-    const int iters = (n + kSlices - 1) >> kSliceShift;
-    {
-      double mom[kTop + 1], rr[kTop + 1];
-#pragma unroll
-      for (int d = 0; d <= kTop; ++d) mom[d] = rr[d] = 0.0;
-      for (int j0 = 0; j0 < iters; j0 += kReseedLarge) {
-        if constexpr (RHS == LSSVR_RHS_SIN) {
-          const double x0 = fma((double)(s + kSlices * j0), step, a);
-          th0 = p.rhs_omega * x0;
-          sincos_tab(th0, rs, rc, p.trig);
-          rs *= kappa;
-          rc *= kappa;
-        }
-        const int j1 = min(j0 + kReseedLarge, iters);
-        for (int j = j0; j < j1; ++j) {
-          const int k = s + kSlices * j;
-          const bool valid = k < n;
-          // np.linspace / mapdomain, two roundings each; last point = b
-          const double xk = (k == n - 1) ? b : (double)k * step + a;
-          const double tk = dm.off + dm.scl * xk;
-          double phi2;
-          if constexpr (RHS == LSSVR_RHS_SIN) {
-            const double arg = p.rhs_omega * xk;
-            const double delta = fma(-(double)(j - j0), dth4, arg - th0);
-            phi2 = fma(rc, delta, rs);
-            if (__any(valid && !(fabs(delta) < 1.0e-7))) phi2 = kappa * sin_tab(arg, p.trig);
-            const double rs_next = fma(rs, cd, rc * sd);
-            rc = fma(rc, cd, -(rs * sd));
-            rs = rs_next;
-          } else {
-            phi2 = valid ? p.rhs_values[e1 * n + k] * fscale : 0.0;
-          }
-          // a slice past the end contributes zeros: T_0 = 0 makes the whole recurrence vanish
-          const double seed = valid ? 1.0 : 0.0;
-          phi2 *= seed;
-          double Tm2 = seed, Tm1 = tk * seed;
-          const double tt = tk + tk;
-          rr[0] += phi2;
-          mom[1] += Tm1;
-          rr[1] = fma(Tm1, phi2, rr[1]);
-#pragma unroll
-          for (int d = 2; d <= kTop; ++d) {
-            const double Td = fma(tt, Tm1, -Tm2);
-            mom[d] += Td;
-            rr[d] = fma(Td, phi2, rr[d]);
-            Tm2 = Tm1;
-            Tm1 = Td;
-          }
-        }
-      }
-      // the slices of an element add their partial sums into LDS (no shuffles, no registers)
-#pragma unroll
-      for (int d = 1; d <= kTop; ++d) lds_add(&mo[d], mom[d]);
-#pragma unroll
-      for (int d = 0; d <= kTop; ++d) lds_add(&ro[d], rr[d]);
-    }
-    {
-      double sq[15], nb[15];
-#pragma unroll
-      for (int j = 0; j < 15; ++j) sq[j] = nb[j] = 0.0;
-      for (int j = 0; j < iters; ++j) {
-        const int k = s + kSlices * j;
-        const bool valid = k < n;
-        const double xk = (k == n - 1) ? b : (double)k * step + a;
-        const double tk = dm.off + dm.scl * xk;
-        const double seed = valid ? 1.0 : 0.0;
-        double Tm2 = seed, Tm1 = tk * seed;
-        const double tt = tk + tk;
-#pragma unroll
-        for (int d = 2; d <= kTop; ++d) {
-          const double Td = fma(tt, Tm1, -Tm2);
-          if (d - 1 >= 15) nb[d - 1 - 15] = fma(Tm1, Td, nb[d - 1 - 15]);     // T_{d-1} T_d
-          if (d >= 16) sq[d - 16] = fma(Td, Td, sq[d - 16]);                   // T_d^2
-          Tm2 = Tm1;
-          Tm1 = Td;
-        }
-      }
-      // raw sums at the upper moments' places: m_{2j} <- sum T_j^2, m_{2j+1} <- sum T_j T_{j+1}
-#pragma unroll
-      for (int j = 16; j <= 30; ++j) lds_add(&mo[2 * j], sq[j - 16]);
-#pragma unroll
-      for (int j = 15; j <= 29; ++j) lds_add(&mo[2 * j + 1], nb[j - 15]);
-    }
-    wave_lds_sync();
-    // m_0 = n;  m_{2j} = 2 sum T_j^2 - m_0,  m_{2j+1} = 2 sum T_j T_{j+1} - m_1  (slice lane d mod 4)
-    const double m0 = (double)n;
-    const double m1 = mo[1];
-    if (s == 0) mo[0] = m0;
-#pragma unroll
-    for (int d = 31; d <= 60; ++d)
-      if ((d & (kSlices - 1)) == s) mo[d] = fma(2.0, mo[d], -((d & 1) ? m1 : m0));
-  }
-  wave_lds_sync();
-
-  // =========================== phase 2: solve, four elements per round =====================
-  {
-    const int g = lane >> 4;
-    double* const Z = lds + kMomDoubles + kRDoubles + kNDoubles + g * kQuarterDoubles;
-#pragma unroll 1
-    for (int rd = 0; rd < kEPW / 4; ++rd) {
-      const int loc = 4 * rd + g;
-      if (E0 + 4 * rd >= p.ne) break;                    // (uniform: the whole round is past the end)
-      solve_four<false>(p, lane, E0 + loc, Mom + loc * kMomStride, Rv + loc * kRStride, Z,
-                        &kTab.N[0][0], &kTab.Y[0][0]);
-    }
-  }
-}
-
-
 // =============================================================================================
 // The same two phases as TWO kernels with a caller-provided workspace in between (96 doubles per
 // element: lssvr_enhance_work_bytes): the solve kernel then holds nothing but the two columns per
@@ -688,7 +491,7 @@ __global__ __launch_bounds__(64 * kS4Waves, 2) void solve4_kernel(EnhanceArgs p,
   __syncthreads();
   double* const Z = lds + 4 * kS4Stride + g * 64;
   const int64_t eo = (E0 + g < p.ne) ? E0 + g : p.ne - 1;
-  solve_four<true, MODE>(p, lane, E0 + g, lds + g * kS4Stride, lds + g * kS4Stride + 64, Z, Nl, Yl, zl,
+  solve_four<MODE>(p, lane, E0 + g, lds + g * kS4Stride, lds + g * kS4Stride + 64, Z, Nl, Yl, zl,
                          MODE >= 1 ? zws + eo * kZStride : nullptr);
 }
 
@@ -773,18 +576,6 @@ __global__ __launch_bounds__(256) void residual_kernel(EnhanceArgs p, double* __
   double* const o = ws + e * kWsStride + 64;
 #pragma unroll
   for (int i = 0; i <= kTop; ++i) o[i] = rr[i];
-}
-
-hipError_t enhance_large_cheb(const EnhanceArgs& a, hipStream_t s, const LaunchOpts* o) {
-  if (a.M - 2 + 1 > kLP || a.a_values) return hipErrorInvalidValue;
-  const unsigned nxcd = xcd_count();
-  int64_t blocks = (a.ne + kEPW - 1) / kEPW;
-  blocks = (blocks + nxcd - 1) / nxcd * nxcd;
-  if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-  const dim3 grid((unsigned)blocks), block(64);
-  if (a.rhs_id == LSSVR_RHS_SIN)
-    return launch(enhance_large_cheb_kernel<LSSVR_RHS_SIN>, grid, block, s, o, a, nxcd);
-  return launch(enhance_large_cheb_kernel<LSSVR_RHS_ARRAY>, grid, block, s, o, a, nxcd);
 }
 
 // Refinement steps of the two-kernel path by the excess of collocation points over bubble

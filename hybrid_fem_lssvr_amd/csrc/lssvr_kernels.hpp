@@ -90,9 +90,8 @@ inline unsigned cu_count() {
 
 hipError_t enhance_small(const EnhanceArgs& a, hipStream_t s, const LaunchOpts* o = nullptr);
 hipError_t enhance_large(const EnhanceArgs& a, hipStream_t s, const LaunchOpts* o = nullptr);
-// Poisson rows, any M <= 33: Chebyshev-moment Gram, 16 elements per wave (enhance_large_cheb.hip)
-hipError_t enhance_large_cheb(const EnhanceArgs& a, hipStream_t s, const LaunchOpts* o = nullptr);
-// ... as two kernels with a workspace of enhance_moment_ws_bytes(ne, M, n) bytes in between
+// Poisson rows, any M <= 33: Chebyshev-moment Gram (enhance_large_cheb.hip, enhance_large_parity.hip): a
+// sequence of kernels with a workspace of enhance_moment_ws_bytes(ne, M, n) bytes in between
 int enhance_refine_steps(int M, int n);
 int64_t enhance_moment_ws_bytes(int64_t ne, int M, int n);
 hipError_t enhance_large_split(const EnhanceArgs& a, void* work, hipStream_t s, const LaunchOpts* o = nullptr);

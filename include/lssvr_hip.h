@@ -57,12 +57,13 @@ extern "C" {
                                  pivoting, two steps of iterative refinement.  n_colloc <= 64,
                                  M <= 33, Poisson and variable-coefficient rows.  <= 1e-12 of
                                  the exact minimiser on every BASELINE config  */
-#define LSSVR_SOLVER_PRIMAL_MOMENT 3 /* same algorithm as PRIMAL in the two-phase wave mapping of
+#define LSSVR_SOLVER_PRIMAL_MOMENT 3 /* same algorithm as PRIMAL as the kernel sequence of
                                  csrc/enhance_large_cheb.hip (Chebyshev-moment Gram, four systems
-                                 per wave in the LDL^T) for any M, Poisson rows; for A/B
-                                 measurements.  With a workspace (lssvr_enhance_ws) the two-kernel
-                                 form -- what PRIMAL itself runs above M = 22 -- without one the
-                                 fused single kernel (2 resident waves per SIMD, slower) */
+                                 per wave in the LDL^T) for ANY M, Poisson rows -- what PRIMAL
+                                 itself runs above M = 22 with a workspace; for A/B
+                                 measurements below.  lssvr_enhance_ws only: it needs the
+                                 workspace of lssvr_enhance_work_bytes() (LSSVR_ERR_SOLVER
+                                 without one) */
 #define LSSVR_SOLVER_PRIMAL_WAVE 2 /* same algorithm as PRIMAL, forced onto the
                                  wave-per-element / f64-MFMA Gram mapping whatever M is
                                  (PRIMAL picks lane-per-element for M <= 22); for A/B

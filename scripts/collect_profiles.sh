@@ -19,7 +19,6 @@ run sq_s2   --pmc SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_AC
 run sq_s1e7 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/sq_s1e7 -- python3 scripts/prof_enhance.py 10000008,9,16 5 0 wide
 run sq_s1m  --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/sq_s1m -- python3 scripts/prof_enhance.py 1000000,9,16 5 0 narrow
 run sq_w9   --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/sq_w9 -- python3 scripts/prof_enhance.py 1000000,9,16 3 2 narrow
-run sq_mom  --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/sq_mom -- python3 scripts/prof_enhance.py 100000,33,64 3 3 narrow 0 nowork
 run sq_lm   --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/sq_lm -- python3 scripts/prof_enhance.py 100000,33,64 3 2 narrow
 run sq_lm2  --pmc SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/sq_lm2 -- python3 scripts/prof_enhance.py 100000,33,64 3 2 narrow
 run fetchLm --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetchLm -- python3 scripts/prof_enhance.py 100000,33,64 3 2 narrow
@@ -31,7 +30,7 @@ run sq_l    --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCL
 run sq_l2   --pmc SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/sq_l2 -- python3 scripts/prof_enhance.py 100000,33,64 3 0 narrow
 run fetchS  --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetchS -- python3 scripts/prof_shared.py 10000000,9,16 5 narrow
 run writeS  --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/writeS -- python3 scripts/prof_shared.py 10000000,9,16 5 narrow
-python3 scripts/pmc_summary.py $O/fetch $O/write $O/fetchL $O/writeL $O/fetchS $O/writeS $O/sq_s $O/sq_s2 $O/sq_s1m $O/sq_s1e7 $O/sq_w9 $O/sq_l $O/sq_l2 $O/sq_lm $O/sq_lm2 $O/sq_mom $O/sq_d9 $O/sq_d33 > $O/pmc_summary.txt 2>&1
+python3 scripts/pmc_summary.py $O/fetch $O/write $O/fetchL $O/writeL $O/fetchS $O/writeS $O/sq_s $O/sq_s2 $O/sq_s1m $O/sq_s1e7 $O/sq_w9 $O/sq_l $O/sq_l2 $O/sq_lm $O/sq_lm2 $O/sq_d9 $O/sq_d33 > $O/pmc_summary.txt 2>&1
 cp $O/stats/*/*kernel_stats.csv $O/bench_kernel_stats.csv 2>/dev/null
 cp $O/statsL/*/*kernel_stats.csv $O/bench_deg32_kernel_stats.csv 2>/dev/null
 tail -n 60 $O/pmc_summary.txt

@@ -130,11 +130,12 @@ def test_fallback_status_large(dev):
     assert np.all(W[10, 2:] == 0)
 
 
-@pytest.mark.parametrize("M,n,ne", [(33, 64, 24), (33, 64, 1003), (25, 48, 77), (9, 16, 130), (16, 31, 35), (4, 7, 19)])
+@pytest.mark.parametrize("M,n,ne", [(33, 64, 24), (33, 64, 1003), (25, 48, 77), (9, 16, 130), (16, 31, 35), (4, 7, 19),
+                                    (3, 5, 9), (2, 4, 5), (22, 30, 41)])
 def test_moment_wave_mapping_vs_default(dev, M, n, ne):
-    """LSSVR_SOLVER_PRIMAL_MOMENT (csrc/enhance_large_cheb.hip: Chebyshev-moment Gram, sixteen elements
-    per wave, four systems per wave in the DPP LDL^T) against the oracle and the default kernels:
-    every tail of the 16-element blocks and of the 4-element rounds, any M."""
+    """LSSVR_SOLVER_PRIMAL_MOMENT (the kernel sequence of csrc/enhance_large_cheb.hip / enhance_large_parity.hip
+    forced for any M: Chebyshev-moment Gram, four systems per wave in the DPP LDL^T) against the oracle and the
+    default kernels: every tail of the 4-element rounds, degrees from 1 to 32."""
     from hybrid_fem_lssvr_amd import ops
     rng = np.random.default_rng(900 + M + ne)
     nodes = np.cumsum(np.concatenate([[-0.7], rng.uniform(0.01, 0.08, ne)]))
@@ -322,3 +323,19 @@ def test_parity_split_per_element_gamma_and_failures(dev):
     good = [0, 5, 20, 42]
     Wo = orc.enhance_all_vec(nodes, np.nan_to_num(values), M, 1e4, n, global_domain=(0.0, 1.0))
     assert orc.rel_l2_coef(W.cpu().numpy()[good], Wo[good]).max() <= 1e-11
+
+
+def test_moment_solver_needs_workspace(dev):
+    """LSSVR_SOLVER_PRIMAL_MOMENT is the kernel sequence with a workspace in between: without one the
+    call is refused (no silent switch to another kernel), with the default per-device buffer it runs."""
+    from hybrid_fem_lssvr_amd import ops, _capi
+    nodes = np.linspace(-1.0, 1.0, 25)
+    values = np.sin(np.pi * nodes)
+    with pytest.raises(_capi.LssvrHipError, match="workspace"):
+        _enhance(dev, nodes, values, 9, 1e4, 16, global_domain=(-1.0, 1.0), solver=ops.SOLVER_PRIMAL_MOMENT, work=False)
+    lib = _capi.load()
+    assert lib.lssvr_enhance_work_bytes(24, 9, 16, ops.SOLVER_PRIMAL_MOMENT) == 24 * 96 * 8
+    assert lib.lssvr_enhance_work_bytes(24, 9, 16, ops.SOLVER_PRIMAL) == 0
+    W, st = _enhance(dev, nodes, values, 9, 1e4, 16, global_domain=(-1.0, 1.0), solver=ops.SOLVER_PRIMAL_MOMENT)
+    Wd, _ = _enhance(dev, nodes, values, 9, 1e4, 16, global_domain=(-1.0, 1.0))
+    assert np.all(st == 0) and orc.rel_l2_coef(W, Wd).max() <= 1e-12
