@@ -1,7 +1,8 @@
-// Shared pieces of the wave-per-element-pair kernels (enhance_large.hip, enhance_dual.hip):
-// LDS geometry, wave-level helpers, and the in-register LDL^T factor / solve of a padded
-// 32 x 32 symmetric system held one column per lane (two systems per wave, one per
-// 32-lane half).
+// Shared pieces of the wave-level kernels (enhance_large.hip, enhance_large_cheb.hip,
+// enhance_large_parity.hip, enhance_dual.hip): LDS geometry, wave-level helpers, and the
+// in-register LDL^T factor / solve routines -- a padded 32 x 32 system one column per lane, two
+// systems per wave (ldlt_solve_dpp); two columns per lane, four systems per wave
+// (ldlt_solve_dpp4); and its parity-split form (ldlt_parity_*).
 #pragma once
 #include <type_traits>
 #include "lssvr_device.hpp"
@@ -76,90 +77,18 @@ __device__ __forceinline__ double legendre_near_one(int p, double s) {
 
 
 // ---------------------------------------------------------------------------
-// LDL^T factor + solve.  On entry lane (c, h) holds column c of the symmetric matrix of
-// system h in col[0..31] (row index = register index); the right-hand side sits in row
-// kRhsRow of every column (and, by symmetry, is column kRhsRow).  Only the leading
-// nsys x nsys block is factorised.  Lm: this half's 32 x kSL LDS region (aliases the Gram
-// buffer), Z: 32 doubles.  Returns z_c, the solution component of lane c (0 for c >= nsys).
-//
-// Right-looking elimination without square roots: at step j the UNSCALED pivot row
-// a_jc is published through LDS (row j of Lm), every lane reads the pivot d_j = a_jj and
-// the entries a_ji it needs, and updates a_ic -= a_ji * (a_jc / d_j).  Lanes c < j publish
-// zeros (lane j itself publishes the pivot; its own column then cancels to zero, which is
-// harmless: a dead column is never read from registers again), so the stored factor has an exactly zero upper triangle and the backward
-// substitution needs no lane masks.  A zero / negative / non-finite pivot makes 1/d_j
-// inf/NaN or flips signs; every later entry inherits it, so the caller's single finiteness
-// test on the solution detects a breakdown (SPD input => all d_j > 0 is also checked).
+// LDL^T factor + solve of the padded symmetric system, one column per lane: lane (c, h) holds
+// column c of the matrix of system h in col[0..31] (row index = register index); the right-hand
+// side sits in row kRhsRow of every column (and, by symmetry, is column kRhsRow).  Only the
+// leading nsys x nsys block is factorised.  Right-looking elimination without square roots:
+// a_ic -= a_ji (a_jc / d_j).  A zero / negative / non-finite pivot makes 1/d_j inf/NaN or flips
+// signs; every later entry inherits it, so the caller's single finiteness test on the solution
+// detects a breakdown (SPD input => all d_j > 0 is also checked).
 // ---------------------------------------------------------------------------
 constexpr int kRhsRow = kLP - 1;
 
-__device__ __forceinline__ double ldlt_solve(double (&col)[kLP], double* __restrict__ Lm,
-                                             double* __restrict__ Z, int c, int nsys,
-                                             bool& pivots_ok) {
-  // (cc is an opaque copy of c: otherwise hipcc hoists all 31 lane masks (c < j) out of the
-  // caller's element loop and spills them to VGPR lanes.)
-  // (likewise ns for the 31 uniform conditions j < nsys.)
-  int cc = c;
-  asm volatile("" : "+v"(cc));
-  int ns = nsys;
-  asm volatile("" : "+s"(ns));
-  double dmin = 1.0;
-  // Software-pipelined by one step: row j+1 is published as soon as its entries are final
-  // (right after the first update of step j), so its LDS round trip overlaps the remaining
-  // 30-j updates of step j instead of stalling step j+1.
-  Lm[0 * kSL + c] = col[0];
-  wave_lds_sync();
-#pragma unroll
-  for (int j = 0; j < kLP - 1; ++j) {
-    if (j < ns) {
-      const double dj = Lm[j * kSL + j];
-      dmin = fmin(dmin, dj);
-      const double tcj = col[j] * rcp_newton(dj);           // a_jc / d_j
-      // row j+1 of every column first, then publish it
-      col[j + 1] = fma(-Lm[j * kSL + j + 1], tcj, col[j + 1]);
-      if (j + 1 < kLP - 1) Lm[(j + 1) * kSL + c] = (cc < j + 1) ? 0.0 : col[j + 1];
-      if ((j + 2) & 1) col[j + 2] = fma(-Lm[j * kSL + j + 2], tcj, col[j + 2]);
-#pragma unroll
-      for (int i = (j + 3) & ~1; i < kLP; i += 2) {
-        const double2_t l2 = *reinterpret_cast<const double2_t*>(&Lm[j * kSL + i]);
-        col[i] = fma(-l2[0], tcj, col[i]);
-        col[i + 1] = fma(-l2[1], tcj, col[i + 1]);
-      }
-      wave_lds_sync();
-    }
-  }
-  pivots_ok = dmin > 0.0;       // (a NaN pivot slips through fmin but poisons the solution)
-  wave_lds_sync();
-  // backward substitution: L^T z = D^{-1} L^{-1} r.  Lane t keeps Y_t = a_{rhs,t} - sum_{i>t}
-  // a_it z_i (row kRhsRow carried the forward substitution) and z_t = Y_t / d_t.
-  // (row c of the stored factor was published at step c: slot kRhsRow is the fully
-  // eliminated right-hand-side entry a_{rhs,c}, slot c the pivot d_c)
-  double Y = Lm[c * kSL + kRhsRow];
-  double rinv = rcp_newton(Lm[c * kSL + c]);
-  if (c >= nsys) {
-    Y = 0.0;
-    rinv = 0.0;
-  }
-  wave_lds_sync();
-  Lm[c * kSL + c] = 0.0;               // diagonal no longer needed: freezes Y_t after step t
-  asm volatile("" : "+s"(ns));
-#pragma unroll
-  for (int i = kLP - 2; i >= 0; --i) {
-    if (i < ns) {
-      Z[c] = Y * rinv;
-      wave_lds_sync();
-      const double zi = Z[i];
-      const double lit = Lm[c * kSL + i];   // a_ic = d_c L_ic for i > c; 0 for i <= c
-      Y = fma(-lit, zi, Y);
-    }
-  }
-  return (c < nsys) ? Y * rinv : 0.0;
-}
-
-
 // ---------------------------------------------------------------------------
-// The same elimination with NO LDS AT ALL in the factorisation: the pivot row is broadcast
-// by DPP.  gfx90a+ allows DPP on the 64-bit VOP2 v_fmac_f64 for row_newbcast (lane n of each
+// The elimination with NO LDS AT ALL in the factorisation: the pivot row is broadcast by DPP.  gfx90a+ allows DPP on the 64-bit VOP2 v_fmac_f64 for row_newbcast (lane n of each
 // 16-lane row feeds the whole row), so  a_ic -= a_ji t_c  is ONE instruction
 //     v_fmac_f64_dpp col[i], P, ntc  row_newbcast:(i & 15)
 // with P = the register col[j] seen across lanes (lane i holds a_ji).  A system spans two
