@@ -14,13 +14,14 @@
 
 namespace lssvr {
 
-// Chunk length per level: 32 at large sizes (fewest levels, half the workspace), 8 below ~4e6
-// unknowns, where a level of 32-chunks has few threads (1e5 unknowns = 49 waves on 1024
-// SIMDs).  Each row costs ONE division (1/den) and three multiplications in every sweep --
-// with three divisions per row the sweeps were bound by the FP64 division chain: 101 -> 55 us
-// at 1e5 unknowns, 177 -> 91 us at 1e6, 1.4 ms either way at 1e7 (bandwidth / L1 bound).
+// Chunk length per level: 8 at every size (round 2, one run: 1e7 unknowns 432 us against 675 us
+// with chunks of 16 and 818 us with 32 -- a thread's 64-byte run of each array is one batch, a
+// 128-byte line is shared by two neighbouring lanes of the same load instruction; 4 is as fast,
+// with twice the levels).  Each row costs ONE division (1/den) and three multiplications in every
+// sweep -- with three divisions per row the sweeps were bound by the FP64 division chain:
+// 101 -> 55 us at 1e5 unknowns, 177 -> 91 us at 1e6.
 constexpr int kBase = 512;
-static inline int chunk_for(int64_t m) { return m <= (int64_t(1) << 22) ? 8 : 32; }
+static inline int chunk_for(int64_t) { return 8; }
 
 // row i: lo[i] x[i-1] + d[i] x[i] + up[i] x[i+1] = r[i] - [i==0] bl[0]*u0 - [i==m-1] br[0]*u1
 struct TriSys {
@@ -331,8 +332,7 @@ static hipError_t solve_level(const TriSys& s, double* x, double* work, hipStrea
     hipLaunchKernelGGL(tri_base_kernel, dim3(1), dim3((unsigned)kBase), 0, st, s, x, work);
     return hipGetLastError();
   }
-  return chunk_for(s.m) == 8 ? solve_level_chunked<8>(s, x, work, st)
-                             : solve_level_chunked<32>(s, x, work, st);
+  return solve_level_chunked<8>(s, x, work, st);
 }
 
 hipError_t tridiag_dirichlet_solve(const double* diag, const double* off, const double* load,
