@@ -2,7 +2,7 @@
 // both end dofs -- `enforce(A, b, D=basis.get_dofs())` + `solve(A, b)`
 // (Dual.py:129-130).  SURVEY.md section 8(f) "next-1".
 //
-// Algorithm: recursive substructuring (static condensation).  Every kLc-th (8th or 32nd)
+// Algorithm: recursive substructuring (static condensation).  Every kLc-th (8th)
 // unknown is a separator; one thread condenses the kLc-1 unknowns between two
 // separators onto them (two O(1)-state sweeps, nothing stored), the separators
 // form a tridiagonal system kLc times smaller, which is solved the same way
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(kBlock) void tri_expand_kernel(TriSys s, int64_t ns
   const int64_t e = (b + kLc - 1 < s.m) ? b + kLc - 1 : s.m;
   const double xl = j > 0 ? X[j - 1] : 0.0;
   const double xr = j < ns ? X[j] : 0.0;
-  // forward elimination; the modified coefficients stay in registers (kLc-1 = 31 of each),
+  // forward elimination; the modified coefficients stay in registers (kLc-1 = 7 of each),
   // so the back substitution touches memory only to store the solution
   double cc[kLc], yy[kLc];
   double den = 1.0, c = 0.0, y = 0.0;
