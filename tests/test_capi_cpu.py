@@ -98,3 +98,21 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_enhance_work_bytes_is_host_arithmetic():
+    """lssvr_enhance_work_bytes touches no device: the workspace of the kernel sequence above M = 22
+    (96 doubles per element; 32 more where refinement steps follow: n_colloc - (M-2) <= 14), nothing
+    for the lane kernel, the sequence on request for any M (LSSVR_SOLVER_PRIMAL_MOMENT)."""
+    from hybrid_fem_lssvr_amd import _capi
+    lib = _capi.load()
+    wb = lib.lssvr_enhance_work_bytes
+    assert wb(1000, 33, 64, _capi.SOLVER_PRIMAL) == 1000 * 96 * 8            # BASELINE config 4's shape
+    assert wb(1000, 33, 45, _capi.SOLVER_PRIMAL) == 1000 * 128 * 8           # excess 14: one refinement step
+    assert wb(1000, 33, 46, _capi.SOLVER_PRIMAL) == 1000 * 96 * 8
+    assert wb(1000, 23, 21, _capi.SOLVER_PRIMAL) == 1000 * 128 * 8
+    assert wb(1000, 22, 40, _capi.SOLVER_PRIMAL) == 0                        # lane kernel: no workspace
+    assert wb(1000, 9, 16, _capi.SOLVER_PRIMAL) == 0
+    assert wb(1000, 9, 16, _capi.SOLVER_PRIMAL_MOMENT) == 1000 * 96 * 8
+    assert wb(1000, 33, 64, _capi.SOLVER_DUAL) == 0 and wb(1000, 33, 64, _capi.SOLVER_PRIMAL_WAVE) == 0
+    assert wb(0, 33, 64, _capi.SOLVER_PRIMAL) == 0
