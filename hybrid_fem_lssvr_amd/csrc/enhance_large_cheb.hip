@@ -348,9 +348,10 @@ __device__ __forceinline__ void solve_four(const EnhanceArgs& p, const int lane,
 constexpr int kWsStride = kMomentWsStride; // per element: m_0..m_60 at [0, 61), r_0..r_30 at [64, 95)
 
 // Phase 1 alone, ONE ELEMENT PER LANE (no slices, no reduction): 91 accumulators, all points.
+constexpr int kMomBlock = 256;
 template <int RHS>
-__global__ __launch_bounds__(256, 2) void moments_kernel(EnhanceArgs p, double* __restrict__ ws) {
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(kMomBlock, 2) void moments_kernel(EnhanceArgs p, double* __restrict__ ws) {
+  const int64_t e = (int64_t)blockIdx.x * kMomBlock + threadIdx.x;
   const bool live = e < p.ne;
   const int64_t ec = live ? e : p.ne - 1;
   int64_t id = ec;
@@ -598,11 +599,12 @@ hipError_t enhance_large_split(const EnhanceArgs& a, void* work, hipStream_t s, 
   double* const zws = ws + a.ne * kWsStride;
   const int steps = enhance_refine_steps(a.M, a.n);
   const unsigned nxcd = xcd_count();
-  const unsigned b1 = (unsigned)((a.ne + 255) / 256);
+  const unsigned b1 = (unsigned)((a.ne + kMomBlock - 1) / kMomBlock);
   int64_t blocks = (a.ne + 4 * kS4Waves - 1) / (4 * kS4Waves);
   blocks = (blocks + nxcd - 1) / nxcd * nxcd;
   if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-  const dim3 g1(b1), t1(256), g2((unsigned)blocks), t2(64 * kS4Waves);
+  const dim3 g1(b1), t1(kMomBlock), g2((unsigned)blocks), t2(64 * kS4Waves);
+  const dim3 gr((unsigned)((a.ne + 255) / 256)), tr(256);                    // residual_kernel
   // profiled launches: the start stamp of the first kernel and the stop stamp of the last --
   // the duration reported is that of the whole sequence, gaps included
   const bool prof = o && o->start && o->stop;
@@ -625,8 +627,8 @@ hipError_t enhance_large_split(const EnhanceArgs& a, void* work, hipStream_t s, 
   quiet.fail_count = nullptr;
   if ((e = go(solve4_kernel<1>, g2, t2, nullptr, nullptr, quiet, cws, zws, nxcd)) != hipSuccess) return e;
   for (int it = 1; it <= steps; ++it) {
-    e = sine ? go(residual_kernel<LSSVR_RHS_SIN>, g1, t1, nullptr, nullptr, a, ws, czws)
-             : go(residual_kernel<LSSVR_RHS_ARRAY>, g1, t1, nullptr, nullptr, a, ws, czws);
+    e = sine ? go(residual_kernel<LSSVR_RHS_SIN>, gr, tr, nullptr, nullptr, a, ws, czws)
+             : go(residual_kernel<LSSVR_RHS_ARRAY>, gr, tr, nullptr, nullptr, a, ws, czws);
     if (e != hipSuccess) return e;
     e = go(solve4_kernel<2>, g2, t2, nullptr, it == steps ? ev1 : nullptr, it == steps ? a : quiet, cws, zws, nxcd);
     if (e != hipSuccess) return e;
