@@ -313,9 +313,9 @@ __device__ __forceinline__ void enhance_small_body(const EnhanceArgs& p, const u
   }
 }
 
-// MINW = minimum waves per SIMD the register allocator must leave room for.  1: no
-// constraint (142 VGPRs at M = 9 with the trigonometric coefficients in SGPRs: three resident
-// waves); 4: <= 128 VGPRs for launches that can fill a fourth wave slot.
+// MINW = minimum waves per SIMD the register allocator must leave room for.  1 (the only value
+// dispatched): no constraint -- 136 VGPRs at M = 9 with the trigonometric coefficients in SGPRs,
+// three resident waves.
 template <int M, int RHS, bool VC, int MINW>
 __global__ __launch_bounds__(kBlock, MINW) void enhance_small_kernel(EnhanceArgs p) {
   if constexpr (VC) {
@@ -350,12 +350,9 @@ __global__ __launch_bounds__(kBlock) void step_small_kernel(EnhanceArgs p, P1Arg
 template <int M, int RHS, bool VC>
 static hipError_t launch_small(const EnhanceArgs& a, hipStream_t s, const LaunchOpts* o) {
   const unsigned blocks = (unsigned)((a.ne + kBlock - 1) / kBlock);
-  // more than 3 waves per SIMD on the 256-CU chip -> the occupancy-4 build, but only where the
-  // kernel is within a few registers of 128 VGPRs anyway (M <= 9)
-  if constexpr (M <= 9 && !VC) {
-    if (a.ne > 3 * 64 * 4 * 256)
-      return launch(enhance_small_kernel<M, RHS, VC, 4>, dim3(blocks), dim3(kBlock), s, o, a);
-  }
+  // (An occupancy-4 build -- __launch_bounds__(kBlock, 4): 128 VGPRs, a few spills -- used to take
+  // over above 2e5 elements; since the Chebyshev-moment body needs 136 VGPRs it loses: 406 against
+  // 388 us at 1e7 elements, 41.9 against 41.3 at 1e6, same run.)
   return launch(enhance_small_kernel<M, RHS, VC, 1>, dim3(blocks), dim3(kBlock), s, o, a);
 }
 
