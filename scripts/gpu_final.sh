@@ -7,5 +7,8 @@ timeout -k 10 600 python bench.py > gpurun_out/final_bench.json 2> gpurun_out/fi
 python -c "
 import json
 j=json.loads(open('gpurun_out/final_bench.json').read().strip().splitlines()[-1])
-print(j['metric'], j['value'], j['ms_per_step'], j['roofline']['frac'], j['cpu_baseline'])
+print(j['metric'], j['value'], j['ms_per_step'], j['roofline']['frac'])
 "
+timeout -k 10 300 python bench.py --degree 32 --colloc 64 --elements 100000 --domain narrow --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('deg32', j['value'], j['ms_per_step'], j['roofline']['frac'])"
