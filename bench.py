@@ -40,6 +40,11 @@ import subprocess
 import sys
 import time
 
+# Kernel arguments in device memory (the HIP runtime reads this when it initialises; this image's
+# default already): with them in host memory every launch of the 10 us kernel pays 2 us more
+# (measured 11.0 against 9.0 us).
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
