@@ -1,0 +1,50 @@
+"""CPU: the bench line committed under profiles/ (written by bench.py on an MI355X, scripts/collect_profiles.sh)
+carries every field the measurement contract names, with consistent arithmetic."""
+import json
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _line(name):
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        pytest.skip(name + " not collected")
+    return json.loads(open(path).read().strip().splitlines()[-1])
+
+
+def test_default_bench_line_contract():
+    j = _line("r02_bench_n1.json")
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert j["metric"].split(",")[0] == base["metric"].split(",")[0]          # BASELINE's metric
+    assert j["unit"] == "elements/s" and j["higher_is_better"] is True and j["n_gpus"] == 1
+    assert j["dtype"] == "f64" and j["data"] == "synthetic" and j["vs_baseline"] is None
+    assert "workload" in j["config"] and "model" not in j["config"]
+    # value = elements of the K steps / their time
+    ne = j["config"]["elements_total"]
+    assert abs(j["value"] - ne / (j["ms_per_step"] * 1e-3)) <= 1e-6 * j["value"]
+    r = j["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_us_avg"):
+        assert key in r, key
+    assert r["unit"] == "TFLOP/s" and r["bound"] in ("fp64-valu", "mfma", "hbm")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-12
+    # achieved = algorithmic flops per launch / the kernel's average launch duration
+    flops = r["flops_per_element"] * r["elements_per_launch"]
+    assert abs(r["achieved"] - flops / (r["kernel_us_avg"] * 1e-6) / 1e12) <= 1e-9 * r["achieved"]
+    # the dominant kernel fits inside the step it dominates
+    assert r["kernel_us_avg"] * 1e-3 <= 1.05 * j["ms_per_step"]
+    c = j["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in c, key
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
+    assert j["value"] >= 1.0e6                                              # north_star's target
+
+
+@pytest.mark.parametrize("name", ["r02_bench_deg32.json", "r02_bench_1e7.json", "r02_bench_dual_deg8.json"])
+def test_other_bench_lines_are_consistent(name):
+    j = _line(name)
+    r = j["roofline"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-12 and 0.0 < r["frac"] < 1.5
+    assert j["n_gpus"] == 1 and j["steps"] >= 1 and j["unit"] == "elements/s"
