@@ -5,8 +5,8 @@ VALU-issue slots (two wait states; `s_nop N` supplies N+1).  hipcc pads its own 
 but cannot see a DPP modifier inside an `asm` statement, so lssvr_wave.hpp passes every DPP source
 through an `s_nop 1` statement -- and this script proves on the assembly of the actual build that
 nothing (a live-range split copy, a rescheduled instruction) ended up in between.  Second rule checked:
-a VALU write of EXEC (v_cmpx*, v_readlane-free code never has one, hipcc masks with v_cmp + s_and_saveexec)
-needs five wait states before a DPP instruction; an SALU write of EXEC needs none.
+a VALU write of EXEC (v_cmpx*; hipcc masks with v_cmp + s_and_saveexec, so none is expected) needs five
+wait states before a DPP instruction; an SALU write of EXEC needs none.
 
 usage: check_dpp_hazard.py file.s [more.s ...]     (hipcc -S --cuda-device-only output)
 Exit status 1 and a listing if a violation is found.  Run by __graft_entry__.build()."""
