@@ -55,7 +55,10 @@ NE_CONFIG3 = 10000008                      # BASELINE config 3, h = 1/12 on [-41
 FP64_PEAK_TFLOPS = 78.6                    # MI355X vector = matrix FP64 peak (SURVEY.md 8(d):
                                            # 256 CU x 4 SIMD x 32 FLOP/clk x 2.4 GHz); probe below
 HBM_PEAK_GBS = 8000.0
-SAMPLES_PER_ELEMENT = 2                    # u is stitched on the uniform grid of spacing h/2
+SAMPLES_PER_ELEMENT = 2                    # u is stitched on the uniform grid of spacing h/2 (--stitch-samples)
+NE_C5_WIDE = 1000008                       # BASELINE config 5 on [-41667, 41667], h = 1/12 exactly
+NE_C5_NARROW = 1000000                     # ... and on [-1, 1] as BASELINE words it
+HBM_ACHIEVABLE_GBS = 6290.0                # measured stream rate (MI355X_MICROARCH.md), quoted beside the 8 TB/s spec
 
 
 def algorithmic_flops(M, n):
@@ -108,29 +111,34 @@ def _cpu_worker(args):
     os.environ["OMP_NUM_THREADS"] = os.environ["OPENBLAS_NUM_THREADS"] = "1"
     import numpy as np
     from oracle import lssvr_oracle as orc
-    nodes, values, elems, ne, gd, seed = args
+    nodes, values, elems, ne, gd, seed, varcoef = args
     rng = np.random.default_rng(seed)
+    rhs, kw = orc.poisson_rhs, {}
+    if varcoef:
+        a, da, f = orc.varcoef_functions(*orc.varcoef_params())
+        rhs, kw = f, {"coef_a": a, "coef_da": da}
     t0 = time.perf_counter()
     ok = 0
     for i in elems:
         j = int(i)
-        _, s = orc.slsqp_element(orc.poisson_rhs, nodes[j], nodes[j + 1], values[j], values[j + 1],
+        _, s = orc.slsqp_element(rhs, nodes[j], nodes[j + 1], values[j], values[j + 1],
                                  M_DEG8, GAMMA, N_COLLOC, left=(j == 0), right=(j == ne - 1),
-                                 global_domain=gd, rng=rng)
+                                 global_domain=gd, rng=rng, **kw)
         ok += int(s)
     return len(elems), ok, time.perf_counter() - t0
 
 
-def cpu_baseline(nodes_host, values_host, gd, per_core=16):
+def cpu_baseline(nodes_host, values_host, gd, per_core=16, varcoef=False):
     """Times the SLSQP loop on a bounded sample of the same mesh with every host core the
-    box gives us (one process per core, like N copies of the single-threaded reference)."""
+    box gives us (one process per core, like N copies of the single-threaded reference).
+    ``varcoef``: the residual of BASELINE config 5 (an extension of Dual.py:43-44)."""
     import multiprocessing as mp
     import numpy as np
     cores = max(1, min(len(os.sched_getaffinity(0)), 16))
     ne = len(nodes_host) - 1
     sample = np.linspace(0, ne - 1, cores * per_core).astype(np.int64)
     parts = np.array_split(sample, cores)
-    jobs = [(nodes_host, values_host, p, ne, gd, 1000 + k) for k, p in enumerate(parts)]
+    jobs = [(nodes_host, values_host, p, ne, gd, 1000 + k, varcoef) for k, p in enumerate(parts)]
     ctx = mp.get_context("fork")
     t0 = time.perf_counter()
     with ctx.Pool(cores) as pool:
@@ -155,7 +163,9 @@ def cpu_baseline(nodes_host, values_host, gd, per_core=16):
         "kind": "port",
         "sample": f"{done} elements evenly spaced through the same {ne}-element mesh, "
                   f"per-element scipy SLSQP loop (oracle/lssvr_oracle.py::slsqp_element = "
-                  f"Dual.py:20-98), one process per core; {conv}/{done} converged",
+                  f"Dual.py:20-98" + (" with the variable-coefficient residual -a u'' - a' u' - f, an "
+                                      "extension of Dual.py:43-44" if varcoef else "")
+                  + f"), one process per core; {conv}/{done} converged",
         "single_core_value": done / busy,
     }
 
@@ -373,6 +383,16 @@ def main():
                     help="N > 1 only: strong = BASELINE config 3 (1e7 elements in total), weak = 1e5 per GPU")
     ap.add_argument("--solver", choices=["primal", "dual"], default="primal",
                     help="dual: time LSSVR_SOLVER_DUAL (north_star's Gram form) instead of the default solver")
+    ap.add_argument("--config", type=int, choices=[2, 4, 5], default=2,
+                    help="BASELINE config: 2 = degree 8 / 16 points (default; the flags above refine it), "
+                         "4 = degree 32 / 64 points on 1e5 elements of [-1,1], 5 = variable coefficient "
+                         "-(a u')' = f, 1e6 elements, degree 8 / 16 points, tabulated a, a', f")
+    ap.add_argument("--table-layout", choices=["point", "element"], default="point",
+                    help="--config 5: layout of the tabulated a, a', f (point-major t[k, e] is what the lane kernel "
+                         "reads at full HBM rate; the other layout is reported beside it)")
+    ap.add_argument("--stitch-samples", type=int, default=0,
+                    help="N > 1: points per element of the stitched u (0 = report both 1 and 2; value_with_allgather "
+                         "is the 2-point line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the stitch measurements")
     ap.add_argument("--no-second-line", action="store_true", help="N > 1: skip the other scaling mode")
@@ -403,14 +423,23 @@ def main():
 
     import numpy as np
 
+    if args.config == 4:
+        args.degree, args.colloc, args.domain = 32, 64, "narrow"
+        args.elements = args.elements or NE_NARROW
+    if args.config == 5:
+        args.degree, args.colloc = 8, N_COLLOC
     M = args.degree + 1
     n = args.colloc
     multi = world > 1
+    if args.config == 5 and multi:
+        raise SystemExit("bench.py --config 5 is a one-GPU line (N > 1 runs BASELINE config 3)")
     if multi:
         if args.scaling == "strong":
             ne_glob = args.elements or NE_CONFIG3
         else:
             ne_glob = (args.elements or NE_WIDE) * world
+    elif args.config == 5:
+        ne_glob = args.elements or (NE_C5_WIDE if args.domain == "wide" else NE_C5_NARROW)
     else:
         ne_glob = args.elements or (NE_WIDE if args.domain == "wide" else NE_NARROW)
     if args.domain == "wide":
@@ -422,13 +451,16 @@ def main():
     # CPU baseline first (N = 1 only): its worker processes are forked before this process
     # touches the GPU (a forked child of a GPU-initialised process is best avoided on this pool)
     cpu_res = None
-    if not multi and not args.no_cpu_baseline and M == M_DEG8 and n == N_COLLOC and args.solver == "primal":
+    # (wide domain only: on [-1, 1] the SLSQP loop stops converging above ~5e4 elements, SURVEY.md finding 5)
+    if (not multi and not args.no_cpu_baseline and M == M_DEG8 and n == N_COLLOC and args.solver == "primal"
+            and args.domain == "wide"):
         step_h = (hi - lo) / ne_glob
         nodes_h = np.arange(ne_glob + 1, dtype=np.float64) * step_h + lo
         nodes_h[-1] = hi
         values_h = np.sin(np.pi * nodes_h)
         values_h[0] = values_h[-1] = 0.0
-        cpu_res = cpu_baseline(nodes_h, values_h, (lo, hi))
+        cpu_res = cpu_baseline(nodes_h, values_h, (lo, hi), varcoef=(args.config == 5),
+                               per_core=(8 if args.config == 5 else 16))
 
     import torch
     import torch.distributed as dist
@@ -466,6 +498,8 @@ def main():
 
     if multi:
         out = run_multi(args, D, M, n, ne_glob, lo, hi, rank, world, dev, backend)
+    elif args.config == 5:
+        out = run_config5(args, D, M, n, ne_glob, lo, hi, dev, cpu_res)
     else:
         out = run_single(args, D, M, n, ne_glob, lo, hi, dev, cpu_res, use_dist)
     if rank == 0:
@@ -567,6 +601,246 @@ def run_multi(args, D, M, n, ne_glob, lo, hi, rank, world, dev, backend):
         out[second[0]] = second[1]
     if one_rank is not None:
         out["one_rank_same_workload"] = one_rank
+    return out
+
+
+# ----------------------------------------------------------------------------------------
+# N = 1, BASELINE config 5: -(a u')' = f with a tabulated smooth random a(x)
+# ----------------------------------------------------------------------------------------
+C5_BYTES_PER_ELEMENT = 16 + 8 * M_DEG8 + 3 * 8 * N_COLLOC       # x, u, W + rows of f, a, a' (SURVEY.md 8(d)): 472
+
+
+def c5_flops(M, n):
+    """SURVEY.md 8(d) primal form + the row combination rho = a L'' + (a'/scl)(L' - C1): 2 FMAs per
+    row entry and point, (M-2) entries."""
+    return algorithmic_flops(M, n) + 4 * (M - 2) * n
+
+
+def _varcoef_device_tables(xc):
+    """a, a', f at the points ``xc`` (device float64 tensor of any shape), on the DEVICE with torch
+    (synthetic input generation only -- not part of any timed region, not the product): the same
+    formulas as oracle/lssvr_oracle.py::varcoef_functions with SURVEY.md 8(d)'s seed; the accuracy
+    block recomputes the sampled rows with numpy and the kernel is checked against those."""
+    import numpy as np
+    import torch
+    rng = np.random.default_rng(20260130)
+    c = rng.uniform(-1.0, 1.0, 8)
+    phi = rng.uniform(0.0, 2.0 * np.pi, 8)
+    a = torch.ones_like(xc)
+    da = torch.zeros_like(xc)
+    for k in range(1, 9):
+        ang = (k * np.pi) * xc + phi[k - 1]
+        a += (0.5 * c[k - 1] / k) * torch.sin(ang)
+        da += (0.5 * np.pi * c[k - 1]) * torch.cos(ang)
+    f = -da * np.pi * torch.cos(np.pi * xc) + a * np.pi ** 2 * torch.sin(np.pi * xc)
+    return a, da, f
+
+
+def run_config5(args, D, M, n, ne, lo, hi, dev, cpu_res):
+    import numpy as np
+    import torch
+    from hybrid_fem_lssvr_amd import ops
+
+    def build(ne_, lo_, hi_, pm_=True):
+        step = (hi_ - lo_) / ne_
+        nodes = np.arange(ne_ + 1, dtype=np.float64) * step + lo_
+        nodes[-1] = hi_
+        values = np.sin(np.pi * nodes)
+        values[0] = values[-1] = 0.0
+        x = torch.as_tensor(nodes, device=dev)
+        u = torch.as_tensor(values, device=dev)
+        xc = ops.colloc_points(x, n, point_major=pm_)
+        a_c, da_c, f_c = _varcoef_device_tables(xc)
+        xq = ops.quad_points(x, 2)
+        a_q, _, f_q = _varcoef_device_tables(xq)
+        del xc, xq
+        W = torch.empty((ne_, M), dtype=torch.float64, device=dev)
+        st = torch.empty(ne_, dtype=torch.int32, device=dev)
+        bands = ops.p1_assemble(x, 2, rhs_quad=f_q, a_quad=a_q)
+        return dict(nodes=nodes, values=values, x=x, u=u, a=a_c, da=da_c, f=f_c, aq=a_q, fq=f_q, W=W, st=st,
+                    bands=bands, gd=(lo_, hi_), ne=ne_, pm=pm_)
+
+    def enh(w, **kw):
+        return ops.enhance_varcoef(w["x"], w["u"], M, GAMMA, n, w["a"], w["da"], w["f"], global_domain=w["gd"],
+                                   out=w["W"], status=w["st"], point_major=w["pm"], **kw)
+
+    def step_fn(w):
+        def go(stream):
+            ops.p1_assemble(w["x"], 2, rhs_quad=w["fq"], a_quad=w["aq"], out=w["bands"], stream=stream)
+            enh(w, stream=stream)
+        return go
+
+    def timed(w, steps, warmup):
+        go = step_fn(w)
+        st = torch.cuda.current_stream().cuda_stream
+        for _ in range(warmup):
+            go(st)
+        D.barrier()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(steps):
+            go(st)
+        e1.record()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        return e0.elapsed_time(e1) * 1e-3, wall
+
+    steps, warmup = args.steps, args.warmup
+    pm = args.table_layout == "point"
+    w = build(ne, lo, hi, pm)
+    dev_s, wall_s = timed(w, steps, warmup)
+    n_fallback = int(w["st"].sum().item())
+    k_s = sorted(enh(w, profiled=True) for _ in range(min(steps, 50)))
+    k_avg, k_med = sum(k_s) / len(k_s), k_s[len(k_s) // 2]
+
+    # the other table layout on the same mesh (same values transposed; bit-equal W expected)
+    other = None
+    try:
+        W_first = w["W"].clone()
+        wo = dict(w, a=w["a"].t().contiguous(), da=w["da"].t().contiguous(), f=w["f"].t().contiguous(), pm=not pm)
+        do, _ = timed(wo, max(steps // 2, 5), min(warmup, 5))
+        ko = sorted(enh(wo, profiled=True) for _ in range(20))
+        torch.cuda.synchronize()
+        other = {"table_layout": "element-major t[e, k]" if pm else "point-major t[k, e]",
+                 "value": ne * max(steps // 2, 5) / do, "ms_per_step": do / max(steps // 2, 5) * 1e3,
+                 "kernel_us_avg": sum(ko) / len(ko) * 1e6,
+                 "hbm_GBps": C5_BYTES_PER_ELEMENT * ne / (sum(ko) / len(ko)) / 1e9,
+                 "W_bit_equal_to_primary_layout": bool(torch.equal(W_first, wo["W"]))}
+        del wo, W_first
+        enh(w)                                   # leave the primary layout's result in W for the accuracy block
+        torch.cuda.synchronize()
+    except Exception as exc:  # pragma: no cover
+        other = {"error": repr(exc)}
+
+    # accuracy of what was just timed: sampled elements against the 60-digit minimiser of the QP
+    # built from numpy-tabulated a, a', f at np.linspace's points (the device tables above are
+    # torch's sin / cos: they differ from numpy's by an ulp or two, which is an INPUT difference;
+    # so the sampled elements are recomputed by the kernel on numpy-tabulated rows)
+    try:
+        from oracle import lssvr_oracle as orc
+        from oracle import closed_form_mp as cf
+        a_f, da_f, f_f = orc.varcoef_functions(*orc.varcoef_params())
+        sel = np.unique(np.linspace(0, ne - 1, 7).astype(np.int64))
+        idx = torch.as_tensor(sel, device=dev)
+        xs = torch.stack([w["x"][idx], w["x"][idx + 1]], 1).cpu().numpy()
+        accuracy = {"sampled_elements": int(len(sel))}
+        Wk = []
+        for k, i in enumerate(sel):
+            nd = np.array([xs[k, 0], xs[k, 1]])
+            xk = np.linspace(nd[0], nd[1], n)[None, :]
+            Wi, sti = ops.enhance_varcoef(torch.as_tensor(nd, device=dev),   # (one element: either layout)
+                                          torch.as_tensor(w["values"][i:i + 2].copy(), device=dev), M, GAMMA, n,
+                                          torch.as_tensor(a_f(xk), device=dev), torch.as_tensor(da_f(xk), device=dev),
+                                          torch.as_tensor(f_f(xk), device=dev), elem_offset=int(i), ne_global=ne,
+                                          global_domain=w["gd"])
+            Wk.append(Wi.cpu().numpy()[0])
+        Wk = np.array(Wk)
+        if cf.HAVE_MP:
+            tr = cf.truth_all(w["nodes"], w["values"], M, GAMMA, n, f_f, w["gd"], sel, coef_a=a_f, coef_da=da_f)
+            accuracy["rel_l2_vs_60_digit_minimiser"] = float(orc.rel_l2_coef(Wk, tr).max())
+            accuracy["rel_l2_bubble_vs_60_digit_minimiser"] = float(orc.rel_l2_bubble(Wk, tr).max())
+        W_run = w["W"][idx].cpu().numpy()
+        accuracy["rel_l2_timed_rows_vs_numpy_tabulated_rows"] = float(orc.rel_l2_coef(W_run, Wk).max())
+        xq_h = np.linspace(w["nodes"][0], w["nodes"][-1], 20001)
+        norms = ops.eval_error(w["x"], w["W"], torch.as_tensor(xq_h, device=dev)).cpu().numpy()
+        accuracy["rel_l2_vs_sin_pi_x_on_20001_probes"] = float(np.sqrt(norms[0] / norms[1]))
+        accuracy["note"] = ("60-digit minimiser of the QP with a, a', f tabulated by numpy at np.linspace's points; the "
+                            "timed launch reads torch-tabulated rows (an ulp or two away in a, a', f): third figure")
+    except Exception as exc:  # pragma: no cover
+        accuracy = {"error": repr(exc)}
+
+    narrow = None
+    if args.domain == "wide" and not args.elements:
+        wn = build(NE_C5_NARROW, -1.0, 1.0, pm)
+        dn, _ = timed(wn, max(steps // 2, 5), min(warmup, 5))
+        kn = sorted(enh(wn, profiled=True) for _ in range(20))
+        narrow = {"workload": "%d elements on [-1, 1] (BASELINE's wording; the SLSQP baseline does not converge "
+                              "there), same step" % NE_C5_NARROW,
+                  "value": NE_C5_NARROW * max(steps // 2, 5) / dn, "ms_per_step": dn / max(steps // 2, 5) * 1e3,
+                  "kernel_us_avg": sum(kn) / len(kn) * 1e6, "fallback_elements": int(wn["st"].sum().item())}
+        del wn
+
+    flops = c5_flops(M, n)
+    byts = C5_BYTES_PER_ELEMENT
+    gbs = byts * ne / k_avg / 1e9
+    tfl = flops * ne / k_avg / 1e12
+    out = {
+        "metric": "LSSVR-enhanced elements/sec, variable-coefficient -(a u')'=f deg-%d/%d-pt" % (args.degree, n),
+        "value": ne * steps / dev_s,
+        "unit": "elements/s",
+        "n_gpus": 1,
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": dev_s / steps * 1e3,
+        "host_wall_ms_per_step": wall_s / steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": ("BASELINE config 5: -(a u')' = f, a(x) = 1 + 0.5 sum_k c_k sin(k pi x + phi_k)/k (SURVEY.md 8(d), "
+                         "seed 20260130), manufactured u = sin(pi x); %d P1 elements on [%g, %g] (h = %.6g), Legendre "
+                         "degree %d (M = %d), %d collocation points, gamma = 1e4; a, a', f tabulated per element and "
+                         "point (3 x %d doubles per element, resident in HBM, %s); step = element-local P1 assembly "
+                         "(a-weighted stiffness, 2-point Gauss) + per-element Gram + solve: two launches"
+                         % (ne, lo, hi, (hi - lo) / ne, args.degree, M, n, n,
+                            "point-major t[k, e]" if pm else "element-major t[e, k]")),
+            "elements_per_gpu": ne,
+            "elements_total": ne,
+            "parallelism": "one rank",
+            "solver": "primal, BC-eliminated SPD (M-2), direct Gram of the weighted rows, LDL^T (lane per element)",
+            "fallback_elements": n_fallback,
+            "timing": "HIP events around the K steps on the launch stream, device synchronised on both sides",
+        },
+        "roofline": {
+            "bound": "hbm",
+            "why": "arithmetic intensity %.1f flop/B is below the ridge (78.6 TFLOP/s / 8 TB/s = 9.8)" % (flops / byts),
+            "kernel": "enhance_small_kernel<M=%d, %s, varcoef>" % (M, "RHS_ARRAY_PM" if pm else "RHS_ARRAY"),
+            "achieved": gbs,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": gbs / HBM_PEAK_GBS,
+            "frac_of_achievable_6.29TBs": gbs / HBM_ACHIEVABLE_GBS,
+            "bytes_per_element": byts,
+            "elements_per_launch": ne,
+            "kernel_us_avg": k_avg * 1e6,
+            "kernel_us_median": k_med * 1e6,
+            "traffic": None,
+            "traffic_source": None,
+        },
+        "roofline_fp64": {
+            "bound": "fp64-valu",
+            "achieved": tfl,
+            "peak": FP64_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": tfl / FP64_PEAK_TFLOPS,
+            "flops_per_element": flops,
+            "flops_formula": "SURVEY.md 8(d) primal form + 4 (M-2) n for the weighted row combination",
+        },
+        "accuracy": accuracy,
+    }
+    tf = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tf):
+        try:
+            tj = json.load(open(tf))
+            tr_ = tj.get("c5_M%d_n%d_ne%d" % (M, n, ne))
+            if tr_:
+                out["roofline"]["traffic"] = tr_["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = ("profiles/traffic.json (%s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                                     "passes of this kernel at this size, calibrated with "
+                                                     "lssvr_stream_probe; NOT measured in this run"
+                                                     % tj.get("_round", "committed profile"))
+        except Exception:
+            pass
+    if other is not None:
+        out["other_table_layout"] = other
+    if narrow is not None:
+        out["narrow_domain"] = narrow
+    if cpu_res is not None:
+        out["cpu_baseline"] = cpu_res
     return out
 
 
@@ -757,9 +1031,10 @@ def run_single(args, D, M, n, ne_glob, lo, hi, dev, cpu_res, use_dist):
     k_dur = max(k_avg, 1e-9)
     ach_tflops = flops * ne_loc / k_dur / 1e12
     if dual:
-        kernel_name, bound = "enhance_dual_kernel", "mfma"
-        pipe = "FP64: f64 MFMA Gram over the Legendre index + wave-level pivoted factorisation (shared FP64 pipe)"
-        solver_lbl = "dual Gram form (K + I/gamma) alpha = y, equilibrated, pivoted"
+        kernel_name, bound = "enhance_dual_kernel", "fp64-valu"
+        pipe = ("FP64 vector FMA only (row per lane: Gram by scalar FMAs, partial-pivot LU with the pivot row "
+                "through LDS, <= 3 safeguarded refinement steps); no MFMA is issued")
+        solver_lbl = "dual Gram form (K + I/gamma) alpha = y: boundary block pivot, Jacobi equilibration, partial-pivot LU"
     elif M <= 22:
         kernel_name, bound = "enhance_small_kernel<M=%d>" % M, "fp64-valu"
         pipe = ("FP64 vector FMA only (lane per element, no MFMA issued); the FP64 vector and matrix peaks of "

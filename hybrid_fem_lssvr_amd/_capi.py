@@ -16,10 +16,13 @@ IN_TREE_LIB = os.path.join(_HERE, "csrc", "liblssvr_hip.so")
 # test suite and the benchmark always exercise the one in-tree library.
 LIB_PATH = os.environ.get("LSSVR_HIP_LIB") or IN_TREE_LIB
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 RHS_ARRAY = 0
 RHS_SIN = 1
+RHS_ARRAY_PM = 2
+TABLE_ELEMENT_MAJOR = 0
+TABLE_POINT_MAJOR = 1
 SOLVER_PRIMAL = 0
 SOLVER_DUAL = 1
 SOLVER_PRIMAL_WAVE = 2
@@ -61,6 +64,12 @@ SIGNATURES = {
                                        _c_int, _c_int, _c_dbl,
                                        _c_dp, _c_dp, _c_dp,
                                        _c_dp, _c_dp, _c_dp, _c_dp]),
+    "lssvr_enhance_varcoef_work_bytes": (_c_i64, [_c_i64, _c_int, _c_int]),
+    "lssvr_enhance_varcoef_ws": (_c_int, [_c_dp, _c_dp, _c_i64, _c_i64, _c_i64,
+                                          _c_dbl, _c_dbl, _c_dbl, _c_dbl,
+                                          _c_int, _c_int, _c_dbl,
+                                          _c_dp, _c_dp, _c_dp, _c_int,
+                                          _c_dp, _c_dp, _c_dp, _c_dp, _c_i64, _c_dp, C.POINTER(C.c_float)]),
     "lssvr_enhance_subset": (_c_int, [_c_dp, _c_dp, _c_i64, _c_dp, _c_i64, _c_i64, _c_i64,
                                       _c_dbl, _c_dbl, _c_dbl, _c_dbl,
                                       _c_int, _c_int, _c_dbl, _c_dp,
@@ -72,6 +81,7 @@ SIGNATURES = {
                                       _c_int, C.POINTER(_c_dbl), _c_dp, _c_dp,
                                       _c_dp, _c_dp, _c_dp, _c_dp, C.POINTER(C.c_float)]),
     "lssvr_colloc_points": (_c_int, [_c_dp, _c_i64, _c_int, _c_dp, _c_dp]),
+    "lssvr_colloc_points_pm": (_c_int, [_c_dp, _c_i64, _c_int, _c_dp, _c_dp]),
     "lssvr_p1_assemble": (_c_int, [_c_dp, _c_i64, _c_int, _c_int, C.POINTER(_c_dbl), _c_dp, _c_dp,
                                    _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp]),
     "lssvr_quad_points": (_c_int, [_c_dp, _c_i64, _c_int, _c_dp, _c_dp]),
@@ -87,6 +97,7 @@ SIGNATURES = {
     "lssvr_eval_error": (_c_int, [_c_dp, _c_dp, _c_i64, _c_int, _c_dp, _c_i64, C.POINTER(_c_dbl), _c_dp, _c_dp]),
     "lssvr_fp64_probe": (_c_int, [_c_dp, _c_int, _c_int, _c_int, _c_dp]),
     "lssvr_stream_probe": (_c_int, [_c_dp, _c_dp, _c_i64, _c_dp]),
+    "lssvr_row_chunk_probe": (_c_int, [_c_dp, _c_dp, _c_i64, _c_int, _c_int, _c_dp]),
 }
 
 _lib = None

@@ -53,6 +53,8 @@ int fill_enhance_args(lssvr::EnhanceArgs& a, const double* x, const double* u, i
   a.inv_gamma = 1.0 / gamma;
   a.M = M;
   a.n = n_colloc;
+  a.tab_es = n_colloc;      // tabulated arrays: element-major unless set_rhs / the caller says otherwise
+  a.tab_ps = 1;
   a.W = W;
   static const lssvr::TrigTables trig = lssvr::make_trig_tables();
   a.trig = trig;
@@ -69,10 +71,15 @@ int set_rhs(lssvr::EnhanceArgs& a, int rhs_id, const double* rhs_params_host,
     a.rhs_omega = rhs_params_host[1];
     return LSSVR_OK;
   }
-  if (rhs_id == LSSVR_RHS_ARRAY) {
+  if (rhs_id == LSSVR_RHS_ARRAY || rhs_id == LSSVR_RHS_ARRAY_PM) {
     if (need_values && !rhs_values)
       return fail(LSSVR_ERR_RHS, "LSSVR_RHS_ARRAY needs rhs_values[%s*n_colloc]", count_name);
+    a.rhs_id = LSSVR_RHS_ARRAY;
     a.rhs_values = rhs_values;
+    if (rhs_id == LSSVR_RHS_ARRAY_PM) {     // rhs_values[k * count + e]
+      a.tab_es = 1;
+      a.tab_ps = a.ne > 0 ? a.ne : 1;
+    }
     return LSSVR_OK;
   }
   return fail(LSSVR_ERR_RHS, "unknown rhs_id %d", rhs_id);
@@ -112,6 +119,26 @@ int enhance_dispatch(const lssvr::EnhanceArgs& a, int solver_id, hipStream_t s,
   }
   // otherwise the direct Gram on the f64 matrix cores
   return check_launch(lssvr::enhance_large(a, s, o), "enhance_large");
+}
+}  // namespace
+
+namespace {
+// enhance_dispatch, optionally BLOCKING and stamped with the dispatch's own begin / end times
+int dispatch_timed(const lssvr::EnhanceArgs& a, int solver_id, hipStream_t s, void* work,
+                   int64_t work_bytes, float* kernel_ms_host) {
+  if (!kernel_ms_host) return enhance_dispatch(a, solver_id, s, nullptr, work, work_bytes);
+  lssvr::LaunchOpts o;
+  if (hipEventCreate(&o.start) != hipSuccess || hipEventCreate(&o.stop) != hipSuccess)
+    return fail(LSSVR_ERR_LAUNCH, "hipEventCreate failed");
+  int rc = enhance_dispatch(a, solver_id, s, &o, work, work_bytes);
+  if (rc == LSSVR_OK) {
+    hipError_t e = hipEventSynchronize(o.stop);
+    if (e == hipSuccess) e = hipEventElapsedTime(kernel_ms_host, o.start, o.stop);
+    if (e != hipSuccess) rc = fail(LSSVR_ERR_LAUNCH, "profiled launch: %s", hipGetErrorString(e));
+  }
+  (void)hipEventDestroy(o.start);
+  (void)hipEventDestroy(o.stop);
+  return rc;
 }
 }  // namespace
 
@@ -166,21 +193,15 @@ int lssvr_enhance_ws(const double* x, const double* u, int64_t ne, int64_t elem_
       solver_id != LSSVR_SOLVER_PRIMAL_WAVE && solver_id != LSSVR_SOLVER_PRIMAL_MOMENT)
     return fail(LSSVR_ERR_SOLVER, "unknown solver_id %d", solver_id);
   if (work_bytes < 0 || (work_bytes > 0 && !work)) return fail(LSSVR_ERR_NULL, "work / work_bytes inconsistent");
+  // a workspace that is given but too small is an error, not a silent change of kernel (and, in
+  // the near-square regime, of accuracy: the refinement needs its 32 extra doubles per element)
+  const int64_t need = lssvr_enhance_work_bytes(ne, M, n_colloc, solver_id);
+  if (work && work_bytes < need)
+    return fail(LSSVR_ERR_SIZE, "work holds %lld bytes, lssvr_enhance_work_bytes(%lld, %d, %d, %d) = %lld "
+                "(pass work = NULL for the workspace-free kernels)", (long long)work_bytes, (long long)ne, M,
+                n_colloc, solver_id, (long long)need);
   if (ne == 0) return LSSVR_OK;
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (!kernel_ms_host) return enhance_dispatch(a, solver_id, s, nullptr, work, work_bytes);
-  lssvr::LaunchOpts o;
-  if (hipEventCreate(&o.start) != hipSuccess || hipEventCreate(&o.stop) != hipSuccess)
-    return fail(LSSVR_ERR_LAUNCH, "hipEventCreate failed");
-  rc = enhance_dispatch(a, solver_id, s, &o, work, work_bytes);
-  if (rc == LSSVR_OK) {
-    hipError_t e = hipEventSynchronize(o.stop);
-    if (e == hipSuccess) e = hipEventElapsedTime(kernel_ms_host, o.start, o.stop);
-    if (e != hipSuccess) rc = fail(LSSVR_ERR_LAUNCH, "profiled launch: %s", hipGetErrorString(e));
-  }
-  (void)hipEventDestroy(o.start);
-  (void)hipEventDestroy(o.stop);
-  return rc;
+  return dispatch_timed(a, solver_id, reinterpret_cast<hipStream_t>(stream), work, work_bytes, kernel_ms_host);
 }
 
 int lssvr_enhance_profiled(const double* x, const double* u, int64_t ne, int64_t elem_offset,
@@ -200,18 +221,7 @@ int lssvr_enhance_profiled(const double* x, const double* u, int64_t ne, int64_t
   if (solver_id != LSSVR_SOLVER_PRIMAL && solver_id != LSSVR_SOLVER_DUAL &&
       solver_id != LSSVR_SOLVER_PRIMAL_WAVE && solver_id != LSSVR_SOLVER_PRIMAL_MOMENT)
     return fail(LSSVR_ERR_SOLVER, "unknown solver_id %d", solver_id);
-  lssvr::LaunchOpts o;
-  if (hipEventCreate(&o.start) != hipSuccess || hipEventCreate(&o.stop) != hipSuccess)
-    return fail(LSSVR_ERR_LAUNCH, "hipEventCreate failed");
-  rc = enhance_dispatch(a, solver_id, reinterpret_cast<hipStream_t>(stream), &o);
-  if (rc == LSSVR_OK) {
-    hipError_t e = hipEventSynchronize(o.stop);
-    if (e == hipSuccess) e = hipEventElapsedTime(kernel_ms_host, o.start, o.stop);
-    if (e != hipSuccess) rc = fail(LSSVR_ERR_LAUNCH, "profiled launch: %s", hipGetErrorString(e));
-  }
-  (void)hipEventDestroy(o.start);
-  (void)hipEventDestroy(o.stop);
-  return rc;
+  return dispatch_timed(a, solver_id, reinterpret_cast<hipStream_t>(stream), nullptr, 0, kernel_ms_host);
 }
 
 int lssvr_step(const double* x, const double* u, int64_t ne, int64_t elem_offset,
@@ -260,21 +270,50 @@ int lssvr_enhance_varcoef(const double* x, const double* u, int64_t ne, int64_t 
                           const double* a_values, const double* da_values,
                           const double* rhs_values, double* W, int32_t* status,
                           int32_t* fail_count, void* stream) {
+  return lssvr_enhance_varcoef_ws(x, u, ne, elem_offset, ne_global, gxmin, gxmax, bc_left, bc_right, M,
+                                  n_colloc, gamma, a_values, da_values, rhs_values, LSSVR_TABLE_ELEMENT_MAJOR,
+                                  W, status, fail_count, nullptr, 0, stream, nullptr);
+}
+
+int64_t lssvr_enhance_varcoef_work_bytes(int64_t ne, int M, int n_colloc) {
+  (void)ne; (void)M; (void)n_colloc;
+  return 0;
+}
+
+int lssvr_enhance_varcoef_ws(const double* x, const double* u, int64_t ne, int64_t elem_offset,
+                             int64_t ne_global, double gxmin, double gxmax, double bc_left,
+                             double bc_right, int M, int n_colloc, double gamma,
+                             const double* a_values, const double* da_values,
+                             const double* rhs_values, int table_layout, double* W, int32_t* status,
+                             int32_t* fail_count, void* work, int64_t work_bytes, void* stream,
+                             float* kernel_ms_host) {
   lssvr::EnhanceArgs a;
   int rc = fill_enhance_args(a, x, u, ne, elem_offset, ne_global, gxmin, gxmax, bc_left, bc_right,
                              M, n_colloc, gamma, W);
   if (rc != LSSVR_OK) return rc;
   if (ne > 0 && (!a_values || !da_values || !rhs_values))
     return fail(LSSVR_ERR_NULL, "a_values, da_values and rhs_values must be non-NULL");
+  if (table_layout != LSSVR_TABLE_ELEMENT_MAJOR && table_layout != LSSVR_TABLE_POINT_MAJOR)
+    return fail(LSSVR_ERR_SIZE, "unknown table_layout %d", table_layout);
   a.rhs_id = LSSVR_RHS_ARRAY;
   a.rhs_values = rhs_values;
   a.a_values = a_values;
   a.da_values = da_values;
+  if (table_layout == LSSVR_TABLE_POINT_MAJOR) {
+    a.tab_es = 1;
+    a.tab_ps = ne > 0 ? ne : 1;
+  }
   a.status = status;
   a.fail_count = fail_count;
+  if (work_bytes < 0 || (work_bytes > 0 && !work)) return fail(LSSVR_ERR_NULL, "work / work_bytes inconsistent");
+  const int64_t need = lssvr_enhance_varcoef_work_bytes(ne, M, n_colloc);
+  if (work && work_bytes < need)
+    return fail(LSSVR_ERR_SIZE, "work holds %lld bytes, lssvr_enhance_varcoef_work_bytes() = %lld",
+                (long long)work_bytes, (long long)need);
   if (ne == 0) return LSSVR_OK;
   // (n_colloc < M-2: rank-deficient primal normal equations -> the dual Gram solver)
-  return enhance_dispatch(a, LSSVR_SOLVER_PRIMAL, reinterpret_cast<hipStream_t>(stream), nullptr);
+  return dispatch_timed(a, LSSVR_SOLVER_PRIMAL, reinterpret_cast<hipStream_t>(stream), work, work_bytes,
+                        kernel_ms_host);
 }
 
 int lssvr_enhance_subset(const double* x, const double* u, int64_t ne_mesh,
@@ -357,6 +396,14 @@ int lssvr_colloc_points(const double* x, int64_t ne, int n_colloc, double* xc, v
   if (ne > 0 && (!x || !xc)) return fail(LSSVR_ERR_NULL, "x and xc must be non-NULL");
   return check_launch(lssvr::colloc_points(x, ne, n_colloc, xc, reinterpret_cast<hipStream_t>(stream)),
                       "colloc_points");
+}
+
+int lssvr_colloc_points_pm(const double* x, int64_t ne, int n_colloc, double* xc, void* stream) {
+  if (ne < 0) return fail(LSSVR_ERR_SIZE, "ne < 0");
+  if (n_colloc < 2) return fail(LSSVR_ERR_SIZE, "n_colloc < 2");
+  if (ne > 0 && (!x || !xc)) return fail(LSSVR_ERR_NULL, "x and xc must be non-NULL");
+  return check_launch(lssvr::colloc_points(x, ne, n_colloc, xc, reinterpret_cast<hipStream_t>(stream), true),
+                      "colloc_points(point-major)");
 }
 
 int lssvr_p1_assemble(const double* x, int64_t ne, int nquad, int rhs_id,
@@ -471,6 +518,14 @@ int lssvr_stream_probe(const double* src, double* dst, int64_t n, void* stream) 
   if (n < 1) return fail(LSSVR_ERR_SIZE, "n must be >= 1");
   return check_launch(lssvr::stream_probe(src, dst, n, reinterpret_cast<hipStream_t>(stream)),
                       "stream_probe");
+}
+
+int lssvr_row_chunk_probe(const double* src, double* dst, int64_t nrows, int rowlen, int chunk, void* stream) {
+  if (!src || !dst) return fail(LSSVR_ERR_NULL, "src and dst must be non-NULL");
+  if (nrows < 1 || rowlen < 1) return fail(LSSVR_ERR_SIZE, "nrows and rowlen must be >= 1");
+  if (chunk != 8 && chunk != 16) return fail(LSSVR_ERR_SIZE, "chunk must be 8 or 16");
+  return check_launch(lssvr::row_chunk_probe(src, dst, nrows, rowlen, chunk, reinterpret_cast<hipStream_t>(stream)),
+                      "row_chunk_probe");
 }
 
 int lssvr_fp64_probe(double* out, int blocks, int iters, int use_mfma, void* stream) {

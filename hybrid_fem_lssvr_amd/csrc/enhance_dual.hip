@@ -172,7 +172,7 @@ __global__ __launch_bounds__(64) void enhance_dual_kernel(EnhanceArgs p, int nre
   if (is_pt) {
     double fk;
     if constexpr (RHS == LSSVR_RHS_SIN) fk = p.rhs_amp * sin_reduced(p.rhs_omega * xk);
-    else fk = p.rhs_values[e * n + r];
+    else fk = p.rhs_values[e * p.tab_es + r * p.tab_ps];
     ftil = fk * inv_scl2;
   }
   double arow[MP];
@@ -181,8 +181,8 @@ __global__ __launch_bounds__(64) void enhance_dual_kernel(EnhanceArgs p, int nre
     double ak = 1.0, bk = 0.0;
     if constexpr (VC) {
       if (is_pt) {
-        ak = p.a_values[e * n + r];
-        bk = p.da_values[e * n + r] * (0.5 * dm.oldlen);     // a'/scl
+        ak = p.a_values[e * p.tab_es + r * p.tab_ps];
+        bk = p.da_values[e * p.tab_es + r * p.tab_ps] * (0.5 * dm.oldlen);     // a'/scl
       }
     }
     // q_m = L''_{m+2}, r1_m = L'_{m+1}

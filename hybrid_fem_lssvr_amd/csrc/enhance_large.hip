@@ -259,15 +259,15 @@ __global__ __launch_bounds__(kLargeWaves * 64, 3) void enhance_large_kernel(Enha
       if constexpr (RHS == LSSVR_RHS_SIN) {
         fk = p.rhs_amp * sin_reduced_tab(p.rhs_omega * xk, tb.sinc + zi);
       } else {
-        fk = valid ? p.rhs_values[e * n + k] : 0.0;
+        fk = valid ? p.rhs_values[e * p.tab_es + k * p.tab_ps] : 0.0;
       }
       // a padding point contributes a zero row: zero seeds make the whole recurrence zero
       const double seed = valid ? 1.0 : 0.0;
       double phi = -(fk * inv_scl2) * seed;
       double ak = 0.0, bk = 0.0;
       if constexpr (VC) {
-        ak = valid ? p.a_values[e * n + k] : 0.0;
-        bk = valid ? p.da_values[e * n + k] * (0.5 * dm.oldlen) : 0.0;      // a'/scl, no division
+        ak = valid ? p.a_values[e * p.tab_es + k * p.tab_ps] : 0.0;
+        bk = valid ? p.da_values[e * p.tab_es + k * p.tab_ps] * (0.5 * dm.oldlen) : 0.0;      // a'/scl, no division
         phi = -fma(bk, d1, fk * inv_scl2) * seed;
       }
       // Recurrence state across the two column halves: p = L''_{j+2} / c_j, r = L'_{j+2}.

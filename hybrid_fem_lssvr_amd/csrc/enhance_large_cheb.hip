@@ -400,7 +400,7 @@ __global__ __launch_bounds__(kMomBlock, 2) void moments_kernel(EnhanceArgs p, do
         rc = fma(rc, cd, -(rs * sd));
         rs = rs_next;
       } else {
-        phi2 = p.rhs_values[ec * n + k] * fscale;
+        phi2 = p.rhs_values[ec * p.tab_es + k * p.tab_ps] * fscale;
       }
       double Tm2 = 1.0, Tm1 = tk;
       const double tt = tk + tk;
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(256) void residual_kernel(EnhanceArgs p, double* __
         rc = fma(rc, cd, -(rs * sd));
         rs = rs_next;
       } else {
-        phi2 = p.rhs_values[ec * n + k] * fscale;
+        phi2 = p.rhs_values[ec * p.tab_es + k * p.tab_ps] * fscale;
       }
       const double tt = tk + tk;
       double b1 = 0.0, b2 = 0.0;

@@ -110,10 +110,11 @@ __global__ __launch_bounds__(kBlock) void enhance_shared_kernel(EnhanceArgs p,
       constexpr int kK = 8;
       [[maybe_unused]] double* const stg = tile + (tid >> 6) * kSharedTilePerWave<M>;
       [[maybe_unused]] const int64_t e0 = (int64_t)blockIdx.x * kBlock + (tid & ~63);
+      [[maybe_unused]] const bool pm = p.tab_ps != 1;      // point-major table: direct coalesced loads
       for (int k = 0; k < n; ++k) {
         double ft;
         if constexpr (RHS == LSSVR_RHS_ARRAY) {
-          if ((k & (kK - 1)) == 0) {
+          if (!pm && (k & (kK - 1)) == 0) {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -138,7 +139,8 @@ __global__ __launch_bounds__(kBlock) void enhance_shared_kernel(EnhanceArgs p,
           rc = fma(rc, cd, -(rs * sd));
           rs = rs_next;
         } else {
-          ft = stg[lane * (kK + 1) + (k & (kK - 1))] * inv_scl2;
+          ft = (pm ? p.rhs_values[ec * p.tab_es + k * p.tab_ps]
+                   : stg[lane * (kK + 1) + (k & (kK - 1))]) * inv_scl2;
         }
         const double* __restrict__ Pk = op + (int64_t)k * M;
 #pragma unroll

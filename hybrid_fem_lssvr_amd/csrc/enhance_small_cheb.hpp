@@ -210,6 +210,43 @@ __device__ __forceinline__ void enhance_small_body_cheb(const EnhanceArgs& p, co
       // lines per load instruction.
       [[maybe_unused]] double* const stg = tile + (tid >> 6) * kChebTilePerWave<M, RHS>;
       [[maybe_unused]] const int64_t e0 = (int64_t)block * kBlock + (tid & ~63);
+      if constexpr (RHS == LSSVR_RHS_ARRAY_PM) {
+        // POINT-MAJOR table rhs_values[k * ne + e]: consecutive lanes read consecutive doubles, no
+        // staging; the next kPrefetchCheb values are requested before the current ones are used.
+        constexpr int kPF = 4;
+        const int64_t ps = p.tab_ps;
+        const double* const tf = p.rhs_values + ec * p.tab_es;
+        double T[TD];
+        auto accumulate = [&](const double xk, const double f) {
+          const double tk = dm.off + dm.scl * xk;         // mapdomain, two roundings
+          const double phi2 = f * fscale;
+          T[0] = 1.0;
+          if constexpr (MR > 1) T[1] = tk;
+          const double tt = tk + tk;
+#pragma unroll
+          for (int d = 2; d < MR; ++d) T[d] = fma(tt, T[d - 1], -T[d - 2]);
+          rv[0] += phi2;
+#pragma unroll
+          for (int d = 1; d < MR; ++d) {
+            mom[d] += T[d];
+            P[d] = fma(T[MR - 1], T[d], P[d]);
+            rv[d] = fma(T[d], phi2, rv[d]);
+          }
+        };
+        double cf[kPF];
+#pragma unroll
+        for (int i = 0; i < kPF; ++i) cf[i] = __builtin_nontemporal_load(tf + (int64_t)min(i, n - 1) * ps);
+        for (int k = 0; k < n; k += kPF) {
+          double nf[kPF];
+#pragma unroll
+          for (int i = 0; i < kPF; ++i) nf[i] = __builtin_nontemporal_load(tf + (int64_t)min(k + kPF + i, n - 1) * ps);
+#pragma unroll
+          for (int i = 0; i < kPF; ++i)
+            if (k + i < n) accumulate((k + i == n - 1) ? b : (double)(k + i) * step + a, cf[i]);
+#pragma unroll
+          for (int i = 0; i < kPF; ++i) cf[i] = nf[i];
+        }
+      } else
       for (int k0 = 0; k0 < n; k0 += kReseed) {
         if constexpr (RHS == LSSVR_RHS_SIN) {
           const double x0 = (k0 == 0) ? a : fma((double)k0, step, a);

@@ -37,6 +37,8 @@ constexpr int kStageArr = 64 * (kStageK + 1);
 template <int M, int RHS, bool VC>
 constexpr int kSmallTilePerWave =
     (RHS == LSSVR_RHS_ARRAY && (VC ? 3 : 1) * kStageArr > 64 * M) ? (VC ? 3 : 1) * kStageArr : 64 * M;
+// (RHS == LSSVR_RHS_ARRAY_PM: point-major tables, read directly -- no staging area)
+constexpr int kPrefetch = 4;   // point-major tables: points fetched ahead of their use
 
 template <int M, int RHS, bool VC>
 __device__ __forceinline__ void enhance_small_body(const EnhanceArgs& p, const unsigned block,
@@ -148,28 +150,8 @@ __device__ __forceinline__ void enhance_small_body(const EnhanceArgs& p, const u
       // when every lane then reads its own row).
       [[maybe_unused]] double* const stg = tile + (tid >> 6) * kSmallTilePerWave<M, RHS, VC>;
       [[maybe_unused]] const int64_t e0 = (int64_t)block * kBlock + (tid & ~63);
-      for (int k = 0; k < n; ++k) {
-        if constexpr (RHS == LSSVR_RHS_ARRAY) {
-          if ((k & (kStageK - 1)) == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int i = 0; i < kStageK; ++i) {
-              const int idx = i * 64 + lane;
-              const int row = idx / kStageK, kk = idx % kStageK;
-              const int64_t er = e0 + row;
-              const bool in = (er < p.ne) && (k + kk < n);
-              const int64_t g = in ? er * n + (k + kk) : 0;
-              stg[row * (kStageK + 1) + kk] = in ? p.rhs_values[g] : 0.0;
-              if constexpr (VC) {
-                stg[kStageArr + row * (kStageK + 1) + kk] = in ? p.a_values[g] : 0.0;
-                stg[2 * kStageArr + row * (kStageK + 1) + kk] = in ? p.da_values[g] : 0.0;
-              }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-          }
-        }
+      // one collocation point k with its tabulated values (fk, and for variable coefficients a_k, a'_k)
+      auto point = [&](const int k, const double fk_tab, const double ak, const double dak) {
         const double xk = linspace_at(a, b, dm.oldlen, step, k, n);
         const double tk = dm.off + dm.scl * xk;
         double fk = 0.0, phi;
@@ -182,16 +164,15 @@ __device__ __forceinline__ void enhance_small_body(const EnhanceArgs& p, const u
           rc = fma(rc, cd, -(rs * sd));
           rs = rs_next;
         } else {
-          fk = stg[lane * (kStageK + 1) + (k & (kStageK - 1))];
+          fk = fk_tab;
           phi = -(fk * inv_scl2);
         }
         double rho[MR];
         if constexpr (VC) legendre_d2<MR>(tk, rho);
         else legendre_d2_scaled<MR>(tk, rho);
         if constexpr (VC) {
-          const double ak = stg[kStageArr + lane * (kStageK + 1) + (k & (kStageK - 1))];
           // a'/scl as a'*(h/2): within an ulp of the division, 11 FP64 instructions fewer per point
-          const double bk = stg[2 * kStageArr + lane * (kStageK + 1) + (k & (kStageK - 1))] * (0.5 * dm.oldlen);
+          const double bk = dak * (0.5 * dm.oldlen);
           double r1[MR + 1];
           legendre_d1<MR + 1>(tk, r1);        // r1[m] = L'_{m+1}; need L'_{j+2} = r1[j+1]
 #pragma unroll
@@ -206,6 +187,77 @@ __device__ __forceinline__ void enhance_small_body(const EnhanceArgs& p, const u
             G[tri(i, j)] = fma(rho[i], rho[j], G[tri(i, j)]);
           }
           rv[i] = fma(rho[i], phi, rv[i]);
+        }
+      };
+      if constexpr (RHS == LSSVR_RHS_ARRAY_PM) {
+        // POINT-MAJOR tables t[k * ne + e]: consecutive lanes read consecutive doubles (full 512-byte
+        // runs per wave and instruction), no staging, no LDS; the values of the next kPrefetch points
+        // are requested before the current kPrefetch are worked on (a point is ~110 instructions:
+        // four of them cover the latency of HBM with two resident waves per SIMD).  Past the last
+        // point the index is clamped (in bounds, value unused).
+        const int64_t ps = p.tab_ps;
+        const double* const tf = p.rhs_values + ec * p.tab_es;
+        [[maybe_unused]] const double* const ta = VC ? p.a_values + ec * p.tab_es : nullptr;
+        [[maybe_unused]] const double* const td = VC ? p.da_values + ec * p.tab_es : nullptr;
+        double cf[kPrefetch], ca[kPrefetch], cdv[kPrefetch];
+        auto fetch = [&](const int k, double& f_, double& a_, double& d_) {
+          const int64_t g = (int64_t)min(k, n - 1) * ps;
+          f_ = __builtin_nontemporal_load(tf + g);
+          if constexpr (VC) {
+            a_ = __builtin_nontemporal_load(ta + g);
+            d_ = __builtin_nontemporal_load(td + g);
+          } else {
+            a_ = d_ = 0.0;
+          }
+        };
+#pragma unroll
+        for (int i = 0; i < kPrefetch; ++i) fetch(i, cf[i], ca[i], cdv[i]);
+        for (int k = 0; k < n; k += kPrefetch) {
+          double nf[kPrefetch], na[kPrefetch], nd[kPrefetch];
+#pragma unroll
+          for (int i = 0; i < kPrefetch; ++i) fetch(k + kPrefetch + i, nf[i], na[i], nd[i]);
+#pragma unroll
+          for (int i = 0; i < kPrefetch; ++i)
+            if (k + i < n) point(k + i, cf[i], ca[i], cdv[i]);
+#pragma unroll
+          for (int i = 0; i < kPrefetch; ++i) {
+            cf[i] = nf[i];
+            ca[i] = na[i];
+            cdv[i] = nd[i];
+          }
+        }
+      } else {
+        for (int k = 0; k < n; ++k) {
+          if constexpr (RHS == LSSVR_RHS_ARRAY) {
+            if ((k & (kStageK - 1)) == 0) {
+              __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+#pragma unroll
+              for (int i = 0; i < kStageK; ++i) {
+                const int idx = i * 64 + lane;
+                const int row = idx / kStageK, kk = idx % kStageK;
+                const int64_t er = e0 + row;
+                const bool in = (er < p.ne) && (k + kk < n);
+                const int64_t g = in ? er * n + (k + kk) : 0;
+                stg[row * (kStageK + 1) + kk] = in ? p.rhs_values[g] : 0.0;
+                if constexpr (VC) {
+                  stg[kStageArr + row * (kStageK + 1) + kk] = in ? p.a_values[g] : 0.0;
+                  stg[2 * kStageArr + row * (kStageK + 1) + kk] = in ? p.da_values[g] : 0.0;
+                }
+              }
+              __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+            }
+          }
+          double fk = 0.0, ak = 0.0, dak = 0.0;
+          if constexpr (RHS == LSSVR_RHS_ARRAY) {
+            fk = stg[lane * (kStageK + 1) + (k & (kStageK - 1))];
+            if constexpr (VC) {
+              ak = stg[kStageArr + lane * (kStageK + 1) + (k & (kStageK - 1))];
+              dak = stg[2 * kStageArr + lane * (kStageK + 1) + (k & (kStageK - 1))];
+            }
+          }
+          point(k, fk, ak, dak);
         }
       }
       if constexpr (!VC) G[0] = 9.0 * (double)n;
@@ -385,8 +437,10 @@ static hipError_t launch_step(const EnhanceArgs& e, const P1Args& a, const QuadR
 
 #define LSSVR_SMALL_CASE_ENH(MM)                                                     \
   case MM:                                                                           \
+    if (a.a_values && a.tab_ps != 1) return launch_small<MM, LSSVR_RHS_ARRAY_PM, true>(a, s, o); \
     if (a.a_values) return launch_small<MM, LSSVR_RHS_ARRAY, true>(a, s, o);         \
     if (a.rhs_id == LSSVR_RHS_SIN) return launch_small<MM, LSSVR_RHS_SIN, false>(a, s, o); \
+    if (a.tab_ps != 1) return launch_small<MM, LSSVR_RHS_ARRAY_PM, false>(a, s, o);  \
     return launch_small<MM, LSSVR_RHS_ARRAY, false>(a, s, o);
 #define LSSVR_SMALL_CASE_STEP(MM) \
   case MM:                        \

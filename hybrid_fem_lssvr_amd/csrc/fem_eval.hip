@@ -10,14 +10,16 @@ namespace lssvr {
 // ---------------------------------------------------------------------------
 // np.linspace(x[e], x[e+1], n) for every element  (Dual.py:40)
 // ---------------------------------------------------------------------------
+template <bool PM>
 __global__ __launch_bounds__(kBlock) void colloc_points_kernel(const double* __restrict__ x,
                                                                 int64_t ne, int n,
                                                                 double* __restrict__ xc) {
   const int64_t total = ne * n;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * kBlock) {
-    const int64_t e = i / n;
-    const int k = (int)(i - e * n);
+    // output index i: element-major (e, k) = (i / n, i % n); point-major (k, e) = (i / ne, i % ne)
+    const int64_t e = PM ? i % ne : i / n;
+    const int k = (int)(PM ? i / ne : i - e * n);
     const double a = x[e], b = x[e + 1];
     const double delta = b - a;
     const double step = delta / (double)(n - 1);
@@ -25,11 +27,14 @@ __global__ __launch_bounds__(kBlock) void colloc_points_kernel(const double* __r
   }
 }
 
-hipError_t colloc_points(const double* x, int64_t ne, int n, double* xc, hipStream_t s) {
+hipError_t colloc_points(const double* x, int64_t ne, int n, double* xc, hipStream_t s, bool point_major) {
   if (ne == 0) return hipSuccess;
   const int64_t total = ne * n;
   const unsigned blocks = (unsigned)((total + kBlock - 1) / kBlock < 8192 ? (total + kBlock - 1) / kBlock : 8192);
-  hipLaunchKernelGGL(colloc_points_kernel, dim3(blocks), dim3(kBlock), 0, s, x, ne, n, xc);
+  if (point_major)
+    hipLaunchKernelGGL(colloc_points_kernel<true>, dim3(blocks), dim3(kBlock), 0, s, x, ne, n, xc);
+  else
+    hipLaunchKernelGGL(colloc_points_kernel<false>, dim3(blocks), dim3(kBlock), 0, s, x, ne, n, xc);
   return hipGetLastError();
 }
 
@@ -326,6 +331,48 @@ hipError_t stream_probe(const double* src, double* dst, int64_t n, hipStream_t s
   const int64_t b = (n + kBlock - 1) / kBlock;
   hipLaunchKernelGGL(stream_copy_probe_kernel, dim3((unsigned)(b < 16384 ? b : 16384)),
                      dim3(kBlock), 0, s, src, dst, n);
+  return hipGetLastError();
+}
+
+// The access pattern of the tabulated-input staging of the lane kernels (enhance_small_impl.hpp):
+// a wave owns 64 consecutive rows of `rowlen` doubles and reads them CHUNK columns at a time,
+// consecutive lanes on consecutive doubles of a row (CHUNK*8-byte runs, rows rowlen*8 bytes apart), the
+// next CHUNK columns by later instructions.  Known byte count (nrows*rowlen*8 read, nrows*8 written):
+// calibrates FETCH_SIZE for that pattern (CHUNK = 8: half-line requests) and measures the bandwidth
+// the pattern itself can reach (the full-line stream probe above reaches 6.2 TB/s).
+template <int CHUNK>
+__global__ __launch_bounds__(kBlock) void row_chunk_probe_kernel(const double* __restrict__ src,
+                                                                  double* __restrict__ dst,
+                                                                  int64_t nrows, int rowlen) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nwave = (int64_t)gridDim.x * (kBlock / 64);
+  for (int64_t wv = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); wv * 64 < nrows; wv += nwave) {
+    const int64_t r0 = wv * 64;
+    double acc = 0.0;
+    for (int k0 = 0; k0 < rowlen; k0 += CHUNK) {
+#pragma unroll
+      for (int i = 0; i < CHUNK; ++i) {
+        const int idx = i * 64 + lane;
+        const int64_t row = r0 + idx / CHUNK;
+        const int kk = k0 + idx % CHUNK;
+        if (row < nrows && kk < rowlen) acc += src[row * rowlen + kk];
+      }
+      asm volatile("" : "+v"(acc));      // one batch lands before the next is issued, like the staging
+    }
+    if (r0 + lane < nrows) dst[r0 + lane] = acc;
+  }
+}
+
+hipError_t row_chunk_probe(const double* src, double* dst, int64_t nrows, int rowlen, int chunk,
+                           hipStream_t s) {
+  const int64_t b = (nrows + kBlock - 1) / kBlock;
+  const dim3 grid((unsigned)(b < 65536 ? b : 65536));
+  if (chunk == 16)
+    hipLaunchKernelGGL(row_chunk_probe_kernel<16>, grid, dim3(kBlock), 0, s, src, dst, nrows, rowlen);
+  else if (chunk == 8)
+    hipLaunchKernelGGL(row_chunk_probe_kernel<8>, grid, dim3(kBlock), 0, s, src, dst, nrows, rowlen);
+  else
+    return hipErrorInvalidValue;
   return hipGetLastError();
 }
 

@@ -23,6 +23,9 @@ struct EnhanceArgs {
   const double* rhs_values;
   const double* a_values;   // non-null => variable-coefficient rows
   const double* da_values;
+  // tabulated arrays (rhs_values, a_values, da_values): entry (element e of the launch, point k)
+  // is t[e * tab_es + k * tab_ps] -- element-major (n, 1) or point-major (1, launch count)
+  int64_t tab_es, tab_ps;
   // heterogeneous launches (lssvr_enhance_subset): local element k of the launch is mesh
   // element elem_ids[k] (NULL: k itself) -- node / nodal-value / gamma_values / status / W
   // rows are addressed by the MESH index, the tabulated arrays (rhs_values, a_values,
@@ -104,7 +107,7 @@ constexpr int kSharedMaxM = 33;  // shared-operator path (uniform meshes): coeff
 hipError_t enhance_shared(const EnhanceArgs& a, const double* op, hipStream_t s,
                           const LaunchOpts* o = nullptr);
 
-hipError_t colloc_points(const double* x, int64_t ne, int n, double* xc, hipStream_t s);
+hipError_t colloc_points(const double* x, int64_t ne, int n, double* xc, hipStream_t s, bool point_major = false);
 
 struct QuadRule {
   double xi[5];
@@ -154,5 +157,6 @@ hipError_t eval_error(const double* x, const double* W, int64_t ne, int M, const
 
 hipError_t fp64_probe(double* out, int blocks, int iters, int use_mfma, hipStream_t s);
 hipError_t stream_probe(const double* src, double* dst, int64_t n, hipStream_t s);
+hipError_t row_chunk_probe(const double* src, double* dst, int64_t nrows, int rowlen, int chunk, hipStream_t s);
 
 }  // namespace lssvr

@@ -8,12 +8,13 @@ raises otherwise -- there is no CPU path.
 from __future__ import annotations
 
 import math
+import threading
 
 import torch
 
 from . import _capi
-from ._capi import (RHS_ARRAY, RHS_SIN, SOLVER_DUAL, SOLVER_PRIMAL, SOLVER_PRIMAL_MOMENT,  # noqa: F401
-                    SOLVER_PRIMAL_WAVE)
+from ._capi import (RHS_ARRAY, RHS_ARRAY_PM, RHS_SIN, SOLVER_DUAL, SOLVER_PRIMAL,  # noqa: F401
+                    SOLVER_PRIMAL_MOMENT, SOLVER_PRIMAL_WAVE, TABLE_ELEMENT_MAJOR, TABLE_POINT_MAJOR)
 
 SOLVER_SHARED = 100      # facade-level choice for UNIFORM meshes: routed to lssvr_enhance_shared
 
@@ -77,33 +78,63 @@ def _stream(stream):
 
 
 _WORK = {}
+_WORK_LOCK = threading.Lock()
 
 
-def workspace(lib, device, ne, M, n_colloc, solver):
-    """Device scratch for ``lssvr_enhance_ws`` (``lssvr_enhance_work_bytes``): one buffer per device,
-    grown on demand, reused by every call on that device (calls on different streams of one device
-    that need it concurrently must pass their own ``work=`` tensor).  None when none is needed."""
+def _torch_stream(handle, device):
+    """torch view of a raw hipStream_t handle (0 = the device's default stream)."""
+    if not handle:
+        return torch.cuda.default_stream(device)
+    return torch.cuda.ExternalStream(int(handle), device=device)
+
+
+def workspace(lib, device, ne, M, n_colloc, solver, stream=None):
+    """Device scratch for ``lssvr_enhance_ws`` (``lssvr_enhance_work_bytes``): one buffer per
+    (device, stream), grown on demand.  Calls on ONE stream are ordered, so they may share it;
+    calls on different streams of a device, or from different host threads on different streams,
+    get different buffers (round 2 shared one buffer per device: two concurrent launches above
+    M = 22 raced on the moments between the two kernels).  A buffer that is replaced by a larger
+    one is handed back to the caching allocator only after ``record_stream`` on the stream that
+    may still be reading it.  None when no workspace is needed."""
     nbytes = int(lib.lssvr_enhance_work_bytes(int(ne), int(M), int(n_colloc), int(solver)))
     if nbytes <= 0:
         return None
-    key = (device.type, device.index)
-    buf = _WORK.get(key)
-    if buf is None or buf.numel() * 8 < nbytes:
-        buf = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=device)
-        _WORK[key] = buf
+    handle = _stream(stream)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device(), handle)
+    with _WORK_LOCK:
+        buf = _WORK.get(key)
+        if buf is None or buf.numel() * 8 < nbytes:
+            if buf is not None:
+                buf.record_stream(_torch_stream(handle, device))
+            buf = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=device)
+            _WORK[key] = buf
     return buf
+
+
+def release_workspaces():
+    """Drop every cached workspace (they are kept for the life of the process otherwise)."""
+    with _WORK_LOCK:
+        for (_, _, handle), buf in list(_WORK.items()):
+            buf.record_stream(_torch_stream(handle, buf.device))
+        _WORK.clear()
 
 
 def enhance(x, u, M, gamma, n_colloc=12, *, rhs=(POISSON_AMP, POISSON_OMEGA), rhs_values=None,
             elem_offset=0, ne_global=None, global_domain=None, bc=(0.0, 0.0),
-            solver=SOLVER_PRIMAL, out=None, status=None, fail_count=None, stream=None, work=None):
+            solver=SOLVER_PRIMAL, out=None, status=None, fail_count=None, stream=None, work=None,
+            point_major=False):
     """``solve_lssvr_subproblems`` (Dual.py:139-169) for the shard (x, u).
 
     x, u: float64[ne+1] device tensors.  Returns (W float64[ne, M], status int32[ne]).
     ``rhs`` = (amp, omega) evaluates f = amp*sin(omega*x) in-kernel; ``rhs_values``
-    float64[ne, n_colloc] (f tabulated at ``colloc_points``) overrides it.
-    ``work``: device scratch for the two-kernel path above M = 22 (default: the per-device buffer
-    of :func:`workspace`; ``work=False`` runs the workspace-free kernels).
+    float64[ne, n_colloc] (f tabulated at ``colloc_points``) overrides it;
+    ``point_major=True``: ``rhs_values`` is float64[n_colloc, ne] instead (f tabulated at
+    ``colloc_points(..., point_major=True)``) -- the layout the lane kernels (M <= 22) read at
+    full HBM rate.
+    ``work``: device scratch for the two-kernel path above M = 22 (default: the buffer
+    :func:`workspace` keeps for this device AND stream; ``work=False`` runs the workspace-free
+    kernels -- above M = 22 the single f64-MFMA kernel, about half the speed).  A caller-supplied
+    ``work`` must not be shared by launches that can run concurrently.
     """
     lib = _capi.load()
     _dev(x, "x")
@@ -124,11 +155,11 @@ def enhance(x, u, M, gamma, n_colloc=12, *, rhs=(POISSON_AMP, POISSON_OMEGA), rh
     out, status = _check_buffers(ne, M, n_colloc, x, out=out, status=status, fail_count=fail_count,
                                  rhs_values=rhs_values)
     if rhs_values is not None:
-        rhs_id, params = RHS_ARRAY, None
+        rhs_id, params = (RHS_ARRAY_PM if point_major else RHS_ARRAY), None
     else:
         rhs_id, params = RHS_SIN, _capi.rhs_params(*rhs)
     if work is None:
-        work = workspace(lib, x.device, ne, M, n_colloc, solver)
+        work = workspace(lib, x.device, ne, M, n_colloc, solver, stream)
     elif work is False:
         work = None
     else:
@@ -145,7 +176,8 @@ def enhance(x, u, M, gamma, n_colloc=12, *, rhs=(POISSON_AMP, POISSON_OMEGA), rh
 
 def enhance_subset(x, u, M, gamma, n_colloc, W, *, elem_ids=None, gamma_values=None,
                    rhs=(POISSON_AMP, POISSON_OMEGA), rhs_values=None, elem_offset=0, ne_global=None,
-                   global_domain, bc=(0.0, 0.0), status=None, fail_count=None, stream=None):
+                   global_domain, bc=(0.0, 0.0), status=None, fail_count=None, stream=None,
+                   point_major=False):
     """``lssvr_enhance_subset``: the elements ``elem_ids`` (int64 device tensor of mesh indices;
     None = all) of the shard (x, u) with one (M, n_colloc); per-element ``gamma_values``
     (float64[ne], indexed by mesh element) optional.  Rows go to ``W[id, :M]`` of the caller's
@@ -178,7 +210,7 @@ def enhance_subset(x, u, M, gamma, n_colloc, W, *, elem_ids=None, gamma_values=N
         _dev(rhs_values, "rhs_values")
         if rhs_values.numel() != nsub * n_colloc:
             raise ValueError("rhs_values must hold nsub*n_colloc doubles (indexed by position in elem_ids)")
-        rhs_id, params = RHS_ARRAY, None
+        rhs_id, params = (RHS_ARRAY_PM if point_major else RHS_ARRAY), None
     else:
         rhs_id, params = RHS_SIN, _capi.rhs_params(*rhs)
     rc = lib.lssvr_enhance_subset(_ptr(x), _ptr(u), ne, _ptr(elem_ids), int(nsub), int(elem_offset),
@@ -220,7 +252,7 @@ def build_shared_operator(h, M, gamma, n_colloc, *, device="cuda:0", stream=None
 
 def enhance_shared(x, u, op, M, n_colloc, *, rhs=(POISSON_AMP, POISSON_OMEGA), rhs_values=None,
                    elem_offset=0, ne_global=None, global_domain, bc=(0.0, 0.0), out=None, status=None,
-                   fail_count=None, stream=None, profiled=False):
+                   fail_count=None, stream=None, profiled=False, point_major=False):
     """``lssvr_enhance_shared`` (uniform meshes; the caller vouches for uniformity).  Returns
     (W, status), or the kernel duration in seconds when ``profiled``."""
     import ctypes
@@ -238,7 +270,7 @@ def enhance_shared(x, u, op, M, n_colloc, *, rhs=(POISSON_AMP, POISSON_OMEGA), r
     out, status = _check_buffers(ne, M, n_colloc, x, out=out, status=status, fail_count=fail_count,
                                  rhs_values=rhs_values)
     if rhs_values is not None:
-        rhs_id, params = RHS_ARRAY, None
+        rhs_id, params = (RHS_ARRAY_PM if point_major else RHS_ARRAY), None
     else:
         rhs_id, params = RHS_SIN, _capi.rhs_params(*rhs)
     ms = ctypes.c_float(0.0)
@@ -272,7 +304,7 @@ def enhance_profiled(x, u, M, gamma, n_colloc=12, *, rhs=(POISSON_AMP, POISSON_O
     out, status = _check_buffers(ne, M, n_colloc, x, out=out, status=status)
     ms = ctypes.c_float(0.0)
     if work is None:
-        work = workspace(lib, x.device, ne, M, n_colloc, solver)
+        work = workspace(lib, x.device, ne, M, n_colloc, solver, stream)
     elif work is False:
         work = None
     rc = lib.lssvr_enhance_ws(_ptr(x), _ptr(u), ne, int(elem_offset), int(ne_global),
@@ -352,8 +384,13 @@ class StepPlan:
 
 def enhance_varcoef(x, u, M, gamma, n_colloc, a_values, da_values, rhs_values, *, elem_offset=0,
                     ne_global=None, global_domain=None, bc=(0.0, 0.0), out=None, status=None,
-                    fail_count=None, stream=None):
-    """BASELINE config 5: rows -a (2/h)^2 L'' - a' (2/h) L' (no reference counterpart)."""
+                    fail_count=None, stream=None, profiled=False, point_major=False):
+    """BASELINE config 5: rows -a (2/h)^2 L'' - a' (2/h) L' (no reference counterpart; the
+    operator it generalises is Dual.py:43-44).  ``profiled``: BLOCKING, returns the launch
+    duration in seconds (the dispatch's own begin / end stamps) instead of (W, status).
+    ``point_major``: the three tables are float64[n_colloc, ne] (``t[k, e]``) instead of
+    float64[ne, n_colloc] -- see :func:`colloc_points`; the fast layout for M <= 22."""
+    import ctypes
     lib = _capi.load()
     _dev(x, "x")
     _dev(u, "u")
@@ -370,20 +407,32 @@ def enhance_varcoef(x, u, M, gamma, n_colloc, a_values, da_values, rhs_values, *
     if x.numel() != u.numel() or x.dim() != 1:
         raise ValueError("x and u must be 1-D with equal length ne+1")
     out, status = _check_buffers(ne, M, n_colloc, x, out=out, status=status, fail_count=fail_count)
-    rc = lib.lssvr_enhance_varcoef(_ptr(x), _ptr(u), ne, int(elem_offset), int(ne_global),
-                                   float(global_domain[0]), float(global_domain[1]),
-                                   float(bc[0]), float(bc[1]), int(M), int(n_colloc), float(gamma),
-                                   _ptr(a_values), _ptr(da_values), _ptr(rhs_values),
-                                   _ptr(out), _ptr(status), _ptr(fail_count), _stream(stream))
-    _capi.check(rc, "lssvr_enhance_varcoef")
+    ms = ctypes.c_float(0.0)
+    rc = lib.lssvr_enhance_varcoef_ws(_ptr(x), _ptr(u), ne, int(elem_offset), int(ne_global),
+                                      float(global_domain[0]), float(global_domain[1]),
+                                      float(bc[0]), float(bc[1]), int(M), int(n_colloc), float(gamma),
+                                      _ptr(a_values), _ptr(da_values), _ptr(rhs_values),
+                                      TABLE_POINT_MAJOR if point_major else TABLE_ELEMENT_MAJOR,
+                                      _ptr(out), _ptr(status), _ptr(fail_count), None, 0,
+                                      _stream(stream), ctypes.byref(ms) if profiled else None)
+    _capi.check(rc, "lssvr_enhance_varcoef_ws")
+    if profiled:
+        return ms.value * 1e-3
     return out, status
 
 
-def colloc_points(x, n_colloc, *, stream=None):
-    """``np.linspace(x[e], x[e+1], n)`` for every element (Dual.py:40) -> float64[ne, n]."""
+def colloc_points(x, n_colloc, *, stream=None, point_major=False):
+    """``np.linspace(x[e], x[e+1], n)`` for every element (Dual.py:40) -> float64[ne, n], or
+    float64[n, ne] with ``point_major`` (the same values transposed: tabulate ``rhs_func`` / a / a'
+    on it and pass the tables with ``point_major=True``)."""
     lib = _capi.load()
     _dev(x, "x")
     ne = x.numel() - 1
+    if point_major:
+        xc = torch.empty((n_colloc, ne), dtype=torch.float64, device=x.device)
+        _capi.check(lib.lssvr_colloc_points_pm(_ptr(x), ne, int(n_colloc), _ptr(xc), _stream(stream)),
+                    "lssvr_colloc_points_pm")
+        return xc
     xc = torch.empty((ne, n_colloc), dtype=torch.float64, device=x.device)
     _capi.check(lib.lssvr_colloc_points(_ptr(x), ne, int(n_colloc), _ptr(xc), _stream(stream)),
                 "lssvr_colloc_points")

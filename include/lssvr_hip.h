@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LSSVR_ABI_VERSION 3
+#define LSSVR_ABI_VERSION 4
 
 /* error codes */
 #define LSSVR_OK              0
@@ -44,6 +44,16 @@ extern "C" {
 #define LSSVR_RHS_ARRAY  0  /* rhs_values[e*n_colloc + k] = f(x_k of element e)   */
 #define LSSVR_RHS_SIN    1  /* f(x) = p[0] * sin(p[1] * x), rounded like numpy's
                                `amp * np.sin(omega * x)`; Poisson: p = {pi^2, pi} */
+#define LSSVR_RHS_ARRAY_PM 2 /* the same table POINT-major: rhs_values[k*ne + e] (ne = the launch's
+                               element count; lssvr_enhance_subset: nsub, e = position in elem_ids).
+                               The layout the lane-per-element kernels (M <= 22) read at full
+                               HBM rate -- consecutive lanes = consecutive elements, no staging;
+                               element-major rows reach them as 64-byte half-line requests, which
+                               the memory system serves at ~3.3 TB/s.  ABI 4 */
+
+/* layout of the tabulated arrays of lssvr_enhance_varcoef_ws (a_values, da_values, rhs_values) */
+#define LSSVR_TABLE_ELEMENT_MAJOR 0  /* t[e*n_colloc + k]: what lssvr_colloc_points produces       */
+#define LSSVR_TABLE_POINT_MAJOR   1  /* t[k*ne + e]: see LSSVR_RHS_ARRAY_PM                         */
 
 /* per-element solver */
 #define LSSVR_SOLVER_PRIMAL 0 /* BC-eliminated primal normal equations, (M-2) SPD, LDL^T
@@ -126,8 +136,11 @@ int lssvr_enhance(const double* x, const double* u, int64_t ne,
  * element; 5e-14 instead of 1e-6 at M = 33, n_colloc = 31 -- DESIGN.md section 2).  Every other
  * case behaves exactly like lssvr_enhance.
  *   lssvr_enhance_work_bytes(ne, M, n_colloc, solver_id)   bytes `work` must hold (0: none needed)
- *   work / work_bytes      device scratch, contents undefined afterwards; too small or NULL: the
- *                          workspace-free kernels run
+ *   work / work_bytes      device scratch, contents undefined afterwards.  NULL: the workspace-free
+ *                          kernels run (above M = 22 the single f64-MFMA kernel: about half the
+ *                          speed, no near-square refinement).  Non-NULL but smaller than
+ *                          lssvr_enhance_work_bytes(): LSSVR_ERR_SIZE (ABI 4; ABI 3 fell back
+ *                          silently)
  *   kernel_ms_host != NULL BLOCKING measurement aid like lssvr_enhance_profiled: the duration of
  *                          the launch (of the PAIR of kernels, gap included, on the split path)
  */
@@ -187,6 +200,23 @@ int lssvr_enhance_varcoef(const double* x, const double* u, int64_t ne,
                           double* W, int32_t* status, int32_t* fail_count, void* stream);
 
 /*
+ * lssvr_enhance_varcoef_ws -- lssvr_enhance_varcoef with a caller workspace and the measurement aid
+ * of lssvr_enhance_ws (ABI 4).  lssvr_enhance_varcoef_work_bytes(ne, M, n_colloc) bytes (0: none
+ * needed); work == NULL runs the workspace-free kernels; too small: LSSVR_ERR_SIZE.
+ * table_layout: LSSVR_TABLE_* of a_values / da_values / rhs_values (all three alike).
+ * kernel_ms_host != NULL: BLOCKING, the duration of the launch (bench.py's roofline).
+ */
+int64_t lssvr_enhance_varcoef_work_bytes(int64_t ne, int M, int n_colloc);
+int lssvr_enhance_varcoef_ws(const double* x, const double* u, int64_t ne,
+                             int64_t elem_offset, int64_t ne_global,
+                             double gxmin, double gxmax, double bc_left, double bc_right,
+                             int M, int n_colloc, double gamma,
+                             const double* a_values, const double* da_values,
+                             const double* rhs_values, int table_layout,
+                             double* W, int32_t* status, int32_t* fail_count,
+                             void* work, int64_t work_bytes, void* stream, float* kernel_ms_host);
+
+/*
  * lssvr_enhance_subset -- heterogeneous meshes (per-element gamma, degree and
  * collocation count; the reference has one lssvr_M / lssvr_gamma for the whole mesh,
  * Dual.py:101).  Enhances the nsub elements elem_ids[0..nsub) of a shard of ne_mesh elements
@@ -241,6 +271,9 @@ int lssvr_enhance_shared(const double* x, const double* u, int64_t ne,
  * Lets the host tabulate an arbitrary `rhs_func` for LSSVR_RHS_ARRAY.
  */
 int lssvr_colloc_points(const double* x, int64_t ne, int n_colloc, double* xc, void* stream);
+/* the same abscissae POINT-major, xc[k*ne + e] (ABI 4): tabulate a function on it and the table is
+ * in LSSVR_RHS_ARRAY_PM / LSSVR_TABLE_POINT_MAJOR layout */
+int lssvr_colloc_points_pm(const double* x, int64_t ne, int n_colloc, double* xc, void* stream);
 
 /*
  * lssvr_p1_assemble -- element-local P1 stiffness and load and their scatter to
@@ -349,6 +382,15 @@ int lssvr_fp64_probe(double* out, int blocks, int iters, int use_mfma, void* str
  * kernels' access width, used to calibrate rocprofv3's FETCH_SIZE / WRITE_SIZE.
  */
 int lssvr_stream_probe(const double* src, double* dst, int64_t n, void* stream);
+
+/*
+ * lssvr_row_chunk_probe -- dst[r] = sum of row r of src[nrows*rowlen], read the way the lane
+ * kernels stage tabulated inputs: a wave owns 64 rows and reads `chunk` (8 or 16) columns of them per
+ * batch, consecutive lanes on consecutive doubles (chunk*8-byte runs, rowlen*8 bytes apart).
+ * nrows*rowlen*8 bytes read, nrows*8 written: calibrates FETCH_SIZE for that pattern (chunk = 8:
+ * half-line requests) and measures the bandwidth the pattern reaches (BASELINE config 5's a, a', f rows).
+ */
+int lssvr_row_chunk_probe(const double* src, double* dst, int64_t nrows, int rowlen, int chunk, void* stream);
 
 #ifdef __cplusplus
 }

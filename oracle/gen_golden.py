@@ -19,7 +19,13 @@ Every fixture stores, per element: the inputs, the reference's SLSQP output
 (seeded, Dual.py:81 draws from numpy's global RNG), and the extended-precision
 closed-form minimiser of the same QP (``oracle/closed_form_mp.py``).
 
-Usage:  python oracle/gen_golden.py [--only G1,G2,...]
+Nodal values come from ``oracle.lssvr_oracle.fem_p1_solve_golden_v1`` -- a FROZEN copy of the P1
+stand-in as it was when the committed fixtures were written -- so that a regeneration
+reproduces their inputs bit for bit (``--verify`` checks that, and reruns the reference on
+the stored inputs; tests/test_oracle_golden.py does the same on every CPU run in the build
+container).
+
+Usage:  python oracle/gen_golden.py [--only G1,G2,...] | --verify
 """
 from __future__ import annotations
 
@@ -115,7 +121,7 @@ def run_reference(mod, nodes, values, M, gamma, n, elements, global_domain, seed
 
 def make_case(mod, name, lo, hi, ne, M, gamma, n, elements=None, truth=True):
     nodes = np.linspace(lo, hi, ne + 1)                      # Dual.py:112
-    values = orc.fem_p1_solve(nodes)                         # stands in for Dual.py:127-135
+    values = orc.fem_p1_solve_golden_v1(nodes)               # stands in for Dual.py:127-135 (FROZEN)
     if elements is None:
         elements = np.arange(ne)
     elements = np.asarray(elements, dtype=np.int64)
@@ -142,7 +148,7 @@ def make_eval_case(mod, name):
     out-of-range and NaN points; expected element indices from the literal scan."""
     lo, hi, ne, M, gamma, n = -1.0, 1.0, 24, 8, 1e4, 12
     nodes = np.linspace(lo, hi, ne + 1)
-    values = orc.fem_p1_solve(nodes)
+    values = orc.fem_p1_solve_golden_v1(nodes)
     solver = mod.FEMLSSVRPrimalSolver(ne + 1, lssvr_M=M, lssvr_gamma=gamma, global_domain=(lo, hi))
     solver.fem_nodes = nodes
     solver.fem_values = values
@@ -165,10 +171,74 @@ def make_eval_case(mod, name):
           f"elem equal={np.array_equal(eo, elem)}")
 
 
+def rerun_on_stored_inputs(mod, g, limit=None):
+    """The reference on a fixture's STORED inputs (``nodes_sel``, ``values_sel``; same per-element
+    seeds as :func:`run_reference`): returns coefficients to compare with ``coef_ref`` -- bit for
+    bit on the numpy / scipy versions that wrote the fixture.  ``limit``: first k elements only."""
+    lo, hi, ne = float(g["lo"]), float(g["hi"]), int(g["ne"])
+    M, n, gamma = int(g["M"]), int(g["n"]), float(g["gamma"])
+    out = []
+    with colloc_count(mod, n):
+        for k, i in enumerate(g["elements"][:limit]):
+            np.random.seed(1234 + int(i) % 100000)
+            with contextlib.redirect_stdout(io.StringIO()):
+                fn = mod.lssvr_primal(
+                    mod.poisson_rhs, [g["nodes_sel"][k, 0], g["nodes_sel"][k, 1]],
+                    g["values_sel"][k, 0], g["values_sel"][k, 1], M, gamma,
+                    is_left_boundary=(int(i) == 0), is_right_boundary=(int(i) == ne - 1),
+                    global_domain_range=(lo, hi))
+            out.append(np.array(fn.coef, dtype=np.float64))
+    return np.array(out)
+
+
+def rerun_eval_case(mod, g):
+    """G7 on its stored inputs: the reference's loop (seed 777) and ``evaluate_solution``."""
+    nodes, values = g["nodes"], g["values"]
+    solver = mod.FEMLSSVRPrimalSolver(len(nodes), lssvr_M=int(g["M"]), lssvr_gamma=float(g["gamma"]),
+                                      global_domain=(float(nodes[0]), float(nodes[-1])))
+    solver.fem_nodes = nodes
+    solver.fem_values = values
+    np.random.seed(777)
+    with colloc_count(mod, int(g["n"])), contextlib.redirect_stdout(io.StringIO()):
+        solver.solve_lssvr_subproblems()
+    W = np.array([f.coef for f in solver.lssvr_functions])
+    return W, solver.evaluate_solution(g["xq"])
+
+
+def verify():
+    """Every committed fixture against (1) the frozen P1 stand-in (inputs) and (2) the reference
+    rerun on the stored inputs (outputs), bit for bit.  The 1e7-element mesh of G6b takes ~30 s of
+    Thomas elimination in Python; ``tests/test_oracle_golden.py`` runs the same checks without it."""
+    mod = load_reference()
+    bad = 0
+    for fn in sorted(os.listdir(OUT_DIR)):
+        if not fn.endswith(".npz"):
+            continue
+        g = dict(np.load(os.path.join(OUT_DIR, fn), allow_pickle=False))
+        if "elements" not in g:
+            W, u = rerun_eval_case(mod, g)
+            ok_in = np.array_equal(orc.fem_p1_solve_golden_v1(g["nodes"]), g["values"])
+            ok_out = np.array_equal(W, g["W"]) and np.array_equal(u, g["u_ref"], equal_nan=True)
+        else:
+            nodes = np.linspace(float(g["lo"]), float(g["hi"]), int(g["ne"]) + 1)
+            v = orc.fem_p1_solve_golden_v1(nodes)
+            e = g["elements"]
+            ok_in = (np.array_equal(nodes[e], g["nodes_sel"][:, 0]) and np.array_equal(v[e], g["values_sel"][:, 0])
+                     and np.array_equal(v[e + 1], g["values_sel"][:, 1]))
+            ok_out = np.array_equal(rerun_on_stored_inputs(mod, g), g["coef_ref"])
+        print(f"{fn}: inputs regenerate bit-equal: {ok_in}; reference rerun bit-equal: {ok_out}")
+        bad += (not ok_in) + (not ok_out)
+    return bad
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
+    ap.add_argument("--verify", action="store_true",
+                    help="check the committed fixtures instead of writing them")
     args = ap.parse_args()
+    if args.verify:
+        sys.exit(1 if verify() else 0)
     only = set(filter(None, args.only.split(",")))
     os.makedirs(OUT_DIR, exist_ok=True)
     mod = load_reference()

@@ -604,16 +604,48 @@ def fem_p1_solve(nodes, rhs=poisson_rhs, coef_a=None, nquad=2):
     return thomas_dirichlet(diag, off, load)
 
 
+_GOLDEN_V1_XI = (0.5 - 0.5 / np.sqrt(3.0), 0.5 + 0.5 / np.sqrt(3.0))
+
+
+def fem_p1_solve_golden_v1(nodes, rhs=poisson_rhs):
+    """FROZEN: the P1 stand-in exactly as it was when ``tests/golden/G*.npz`` were written
+    (2-point Gauss load in this operation order, Thomas elimination at every size).  The
+    fixtures' ``values_sel`` are its output bit for bit; ``oracle/gen_golden.py`` calls this and
+    nothing else for nodal values, so a regeneration reproduces the committed inputs.  Do not
+    edit -- :func:`fem_p1_solve` is the living restatement (any quadrature order, LAPACK banded
+    solve on large meshes: nodal values 3e-11 away at 1e5 elements)."""
+    nodes = np.asarray(nodes, dtype=np.float64)
+    a = nodes[:-1]
+    b = nodes[1:]
+    h = b - a
+    x1 = a + h * _GOLDEN_V1_XI[0]
+    x2 = a + h * _GOLDEN_V1_XI[1]
+    f1 = rhs(x1)
+    f2 = rhs(x2)
+    kdiag = np.ones_like(h) / h
+    hw = 0.5 * h
+    fl = hw * (f1 * (1.0 - _GOLDEN_V1_XI[0]) + f2 * (1.0 - _GOLDEN_V1_XI[1]))
+    fr = hw * (f1 * _GOLDEN_V1_XI[0] + f2 * _GOLDEN_V1_XI[1])
+    diag, off, load = p1_scatter(kdiag, fl, fr)
+    return thomas_dirichlet(diag, off, load)
+
+
 # --------------------------------------------------------------------------
 # the reference's own SLSQP loop = the CPU baseline (Dual.py:20-98, 139-169)
 # --------------------------------------------------------------------------
 def slsqp_element(rhs, a, b, u_l, u_r, M, gamma, n=12, left=False, right=False,
-                  global_domain=(-1.0, 1.0), rng=None, bc_left=0.0, bc_right=0.0):
+                  global_domain=(-1.0, 1.0), rng=None, bc_left=0.0, bc_right=0.0,
+                  coef_a=None, coef_da=None):
     """One ``lssvr_primal`` call restated step for step: same unknown vector
     [w(M), e(n)], same objective (Dual.py:46-49), same constraint vector built
     point by point through ``Legendre.deriv(2)`` (Dual.py:43-44,51-78), same start
     (Dual.py:81) and the same SLSQP options with finite-difference derivatives
-    (Dual.py:87-88).  Returns (coef[M], success)."""
+    (Dual.py:87-88).  Returns (coef[M], success).
+
+    ``coef_a`` / ``coef_da`` (callables): the residual of BASELINE config 5,
+    ``-(a u')' - f = -a u'' - a' u' - f`` -- an EXTENSION of Dual.py:43-44 (the reference
+    hard-codes ``-u''``) written the way the reference writes its own residual: one more
+    ``series.deriv(1)(xk)`` per point."""
     from numpy.polynomial.legendre import Legendre
     from scipy.optimize import minimize
 
@@ -630,7 +662,11 @@ def slsqp_element(rhs, a, b, u_l, u_r, M, gamma, n=12, left=False, right=False,
         slack = z[M:M + n]
         rows = []
         for k, xk in enumerate(pts):
-            rows.append(-series.deriv(2)(xk) - rhs(xk) + slack[k])
+            if coef_a is None:
+                rows.append(-series.deriv(2)(xk) - rhs(xk) + slack[k])
+            else:
+                rows.append(-coef_a(xk) * series.deriv(2)(xk) - coef_da(xk) * series.deriv(1)(xk)
+                            - rhs(xk) + slack[k])
         rows.append(series(a) - g_l)
         rows.append(series(b) - g_r)
         return np.array(rows)
@@ -675,6 +711,27 @@ def rel_l2_coef(c, c_ref):
     num = np.sqrt(np.sum((c - c_ref) ** 2 * wgt, axis=-1))
     den = np.sqrt(np.sum(c_ref ** 2 * wgt, axis=-1))
     return num / den
+
+
+def rel_l2_bubble(c, c_ref):
+    """The same weighted norm restricted to the ENHANCEMENT, p >= 2, relative to the bubble's
+    own norm: |sum_{p>=2} d_p L_p| / |sum_{p>=2} c_ref_p L_p|.
+
+    Why it exists: on fine meshes the linear part (w_0, w_1) carries all but ~1.2 h^2 of the
+    element polynomial's norm (1.5e-10 on 1e5 elements of [-1,1], 1.5e-14 on 1e7), so
+    :func:`rel_l2_coef` cannot tell a correct enhancement from none at all there: with
+    ``c[..., 2:] = 0`` it reads 1.5e-14, this function reads exactly 1.  Rows whose reference
+    has no bubble (M = 2, or an element in the linear fallback) give 0 when ``c`` has none either,
+    inf otherwise."""
+    c = np.asarray(c, dtype=np.float64)
+    c_ref = np.asarray(c_ref, dtype=np.float64)
+    wgt = 1.0 / (2.0 * np.arange(c.shape[-1]) + 1.0)
+    wgt[:2] = 0.0
+    num = np.sqrt(np.sum((c - c_ref) ** 2 * wgt, axis=-1))
+    den = np.sqrt(np.sum(c_ref ** 2 * wgt, axis=-1))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        out = np.where(den > 0, num / np.where(den > 0, den, 1.0), np.where(num > 0, np.inf, 0.0))
+    return out
 
 
 def rel_l2_global(W, W_ref, nodes):

@@ -33,3 +33,19 @@ def dev():
     if not torch.cuda.is_available():
         pytest.fail("GPU test selected but no GPU is visible: the HIP path has no CPU fallback")
     return torch.device("cuda:0")
+
+
+@pytest.fixture
+def note(request):
+    """Record a measured quantity next to its bar: appended to gpurun_out/measured_bars.log (merged
+    back from the GPU box) so that bars can be pinned at a stated multiple of what was measured."""
+    def _note(what, value, bar=None):
+        d = os.path.join(ROOT, "gpurun_out")
+        try:
+            os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, "measured_bars.log"), "a") as fh:
+                fh.write("%s :: %s = %.3e%s\n" % (request.node.name, what, float(value),
+                                                   "" if bar is None else "  (bar %.1e)" % bar))
+        except OSError:
+            pass
+    return _note

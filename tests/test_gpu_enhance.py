@@ -19,6 +19,13 @@ pytestmark = pytest.mark.gpu
 
 TOL_TRUTH = 1e-13
 TOL_REF = 1e-10
+# The enhancement itself (Legendre coefficients p >= 2) relative to ITS OWN norm
+# (oracle.rel_l2_bubble): on fine meshes the linear part hides it from rel_l2_coef by 1.2 h^2
+# (a kernel returning no enhancement at all reads 1.5e-14 there on 1e7 elements).  A float64
+# solve gets the bubble to ~3e-16 of itself at every h (measured against the 60-digit
+# minimiser); bars: 1e-13 to the minimiser, 1e-12 to the batched float64 oracle.
+TOL_BUBBLE_TRUTH = 1e-13
+TOL_BUBBLE_ORACLE = 1e-12
 
 
 def _t(a, dev):
@@ -210,9 +217,11 @@ def test_fallback_status_on_degenerate_elements(dev):
     assert orc.rel_l2_coef(W[keep], Wo[keep]).max() <= 1e-12
 
 
-def test_full_size_config2_properties(dev):
+def test_full_size_config2_properties(dev, note):
     """BASELINE config 2 (1e5 elements on [-1,1], degree 8, 16 points): every element
-    against the batched float64 oracle, boundary rows, and the L2 error vs sin(pi x)."""
+    against the batched float64 oracle -- the whole polynomial AND the enhancement on its own
+    (the bubble is 1.3e-10 of the norm here: rel_l2_coef alone would pass with no bubble at
+    all) --, boundary rows, and the L2 error vs sin(pi x)."""
     ne, M, n = 100000, 9, 16
     nodes = np.linspace(-1, 1, ne + 1)
     values = orc.fem_p1_solve(nodes)
@@ -221,6 +230,12 @@ def test_full_size_config2_properties(dev):
     Wo = orc.enhance_all_vec(nodes, values, M, 1e4, n)
     assert orc.rel_l2_coef(W, Wo).max() <= 1e-12
     assert orc.rel_l2_global(W, Wo, nodes) <= 1e-13
+    bub = orc.rel_l2_bubble(W, Wo).max()
+    note("config 2 bubble vs batched oracle, every element", bub, TOL_BUBBLE_ORACLE)
+    assert bub <= TOL_BUBBLE_ORACLE, bub
+    Wz = W.copy()
+    Wz[:, 2:] = 0.0                     # what the old metric could not see
+    assert orc.rel_l2_coef(Wz, Wo).max() <= 1e-9 and orc.rel_l2_bubble(Wz, Wo).min() == 1.0
     # boundary rows: u(x_e) = g_l, u(x_{e+1}) = g_r
     sgn = (-1.0) ** np.arange(M)
     assert np.max(np.abs(W @ sgn - np.concatenate([[0.0], values[1:-1]]))) < 1e-13
@@ -237,12 +252,18 @@ def test_full_size_config2_properties(dev):
         sel = [0, 1, 49999, 50000, 99999]
         tr = cf.truth_all(nodes, values, M, 1e4, n, orc.poisson_rhs, (-1.0, 1.0), sel)
         assert orc.rel_l2_coef(W[sel], tr).max() <= TOL_TRUTH
+        bt = orc.rel_l2_bubble(W[sel], tr).max()
+        note("config 2 bubble vs 60-digit minimiser", bt, TOL_BUBBLE_TRUTH)
+        assert bt <= TOL_BUBBLE_TRUTH, bt
 
 
-def test_full_size_config3_single_gpu(dev):
+def test_full_size_config3_single_gpu(dev, note):
     """BASELINE config 3's mesh (1e7 elements, degree 8, 16 points) on one GPU: every element
-    solved, boundary rows exact everywhere, a 4e4-element sample against the batched oracle and
-    a few elements against the 60-digit minimiser; shard stitching is covered by
+    solved, boundary rows exact everywhere, a 6e4-element sample against the batched oracle and
+    a few elements against the 60-digit minimiser -- whole polynomial and, separately, the
+    enhancement relative to its own norm (1.3e-14 of the polynomial's at this h: invisible to
+    rel_l2_coef).  A device-side check covers EVERY element's bubble: w_2 = -(h^2/8) u''(mid) to
+    O(h^2), i.e. w_2 / (pi^2 h^2 sin(pi x_mid) / 8) -> 1.  Shard stitching is covered by
     test_shard_offsets_boundary_flags and tests/test_distributed_gloo.py."""
     import torch
     from hybrid_fem_lssvr_amd import ops
@@ -257,15 +278,34 @@ def test_full_size_config3_single_gpu(dev):
     right = W.sum(1).cpu().numpy()
     assert np.max(np.abs(left - values[:-1])) < 1e-13
     assert np.max(np.abs(right - values[1:])) < 1e-13
+    worst = 0.0
     for s0 in (0, 4999000, ne - 20000):
         sl = slice(s0, s0 + 20000)
         Wo = orc.enhance_all_vec(nodes[s0:s0 + 20001], values[s0:s0 + 20001], M, 1e4, n,
                                  global_domain=(-1.0, 1.0))
-        assert orc.rel_l2_coef(W[sl].cpu().numpy(), Wo).max() <= 1e-12
+        Wg = W[sl].cpu().numpy()
+        assert orc.rel_l2_coef(Wg, Wo).max() <= 1e-12
+        worst = max(worst, orc.rel_l2_bubble(Wg, Wo).max())
+    note("config 3 bubble vs batched oracle, 6e4 elements", worst, TOL_BUBBLE_ORACLE)
+    assert worst <= TOL_BUBBLE_ORACLE, worst
+    # every element: the leading bubble coefficient against its asymptotic value (the element
+    # mid point away from the zeros of sin, where the ratio is 0/0)
+    xm = 0.5 * (nodes[:-1] + nodes[1:])
+    # bubble = (f/2)(x-a)(b-x) = (f h^2 / 8)(1 - t^2) + O(h^3),  1 - t^2 = (2/3)(L_0 - L_2)
+    lead = -(2.0 / 3.0) * (np.pi ** 2 / 8.0) * (2.0 / ne) ** 2 * np.sin(np.pi * xm)
+    w2 = W[:, 2].cpu().numpy()
+    big = np.abs(np.sin(np.pi * xm)) > 1e-3
+    ratio = w2[big] / lead[big]
+    note("config 3 max |w_2 / asymptote - 1| over all elements", np.max(np.abs(ratio - 1.0)))
+    assert np.max(np.abs(ratio - 1.0)) < 1e-5
     if cf.HAVE_MP:
         sel = [0, 1, 5000000, ne - 1]
         tr = cf.truth_all(nodes, values, M, 1e4, n, orc.poisson_rhs, (-1.0, 1.0), sel)
-        assert orc.rel_l2_coef(W[sel].cpu().numpy(), tr).max() <= TOL_TRUTH
+        Ws = W[sel].cpu().numpy()
+        assert orc.rel_l2_coef(Ws, tr).max() <= TOL_TRUTH
+        bt = orc.rel_l2_bubble(Ws, tr).max()
+        note("config 3 bubble vs 60-digit minimiser", bt, TOL_BUBBLE_TRUTH)
+        assert bt <= TOL_BUBBLE_TRUTH, bt
 
 
 def test_enhance_sharded_single_rank_chunks(dev):
@@ -363,3 +403,140 @@ def test_wrapper_buffer_validation(dev):
     ):
         with pytest.raises(ValueError):
             call()
+
+
+# --------------------------------------------------------------------------------------------
+# cold paths of the lane kernel (enhance_small_cheb.hpp): exact boundary rows on per-lane scratch
+# (cheb_slow_build, taken by a wave with a_max max(|1+t_a|, |1-t_b|) >= 1e-6) and the per-point
+# sin (taken by a wave with any |delta| > 1e-7, i.e. |omega x| >~ 1e9)
+# --------------------------------------------------------------------------------------------
+def _boundary_rows_slow(nodes, M):
+    """The kernel's own predicate, restated with numpy's mapparms arithmetic (Dual.py:56 ->
+    polyutils.mapparms / mapdomain): per element, then per 64-element wave."""
+    a, b = nodes[:-1], nodes[1:]
+    oldlen = b - a
+    off = (b * -1.0 - a * 1.0) / oldlen
+    scl = 2.0 / oldlen
+    ea = 1.0 + (off + scl * a)
+    eb = 1.0 - (off + scl * b)
+    slow = 0.5 * M * (M - 1) * np.maximum(np.abs(ea), np.abs(eb)) >= 1.0e-6
+    pad = np.zeros(-(-len(slow) // 64) * 64, dtype=bool)
+    pad[:len(slow)] = slow
+    return slow, pad.reshape(-1, 64).any(1)
+
+
+COLD_CASES = [(M, ratio) for M in (3, 9, 14, 22) for ratio in (1.0e8, 1.0e10)]
+
+
+@pytest.mark.parametrize("M,ratio", COLD_CASES)
+def test_lane_kernel_exact_boundary_rows_cold_path(dev, note, M, ratio):
+    """|x|/h = 1e8 and 1e10: t(xmin), t(xmax) miss -1, +1 by ~|x|/h eps, the first-order boundary
+    rows no longer hold to 1e-13 and the wave runs cheb_slow_build (the exact Legendre recurrence
+    at the float64 abscissae numpy's mapdomain gives, Dual.py:66-75) -- the default solver, M <= 22.
+    The test restates the kernel's predicate, so it says which branch each case took: every case
+    is on the cold path except (M = 3, 1e8), which sits just inside the first-order range and
+    pins that side of the switch.  Against the 60-digit minimiser of the reference's QP at the
+    same float64 abscissae, the float64 oracle, and the tabulated-rhs path."""
+    import torch
+    from hybrid_fem_lssvr_amd import ops
+    ne, h, n = 150, 0.1, max(16, 2 * M)          # three waves, the last one partial
+    rng = np.random.default_rng(int(M * 7 + np.log10(ratio)))
+    nodes = ratio * h + h * np.arange(ne + 1)
+    values = np.sin(np.pi * nodes) + 0.01 * rng.standard_normal(ne + 1)
+    gd = (nodes[0], nodes[-1])
+    slow_el, slow_wave = _boundary_rows_slow(nodes, M)
+    if (M, ratio) == (3, 1.0e8):
+        assert not slow_wave.any()
+    else:
+        assert slow_wave.all(), (M, ratio, slow_el.mean())
+    W, st = _enhance(dev, nodes, values, M, 1e4, n, global_domain=gd)
+    assert np.all(st == 0)
+    Wo = orc.enhance_all_vec(nodes, values, M, 1e4, n, global_domain=gd)
+    eo = orc.rel_l2_coef(W, Wo).max()
+    note("cold boundary rows M=%d |x|/h=%.0e vs float64 oracle" % (M, ratio), eo, 1e-11)
+    assert eo <= 1e-11, eo
+    # boundary rows hold at the float64 end-point abscissae (what Dual.py:66-75 evaluates)
+    x = _t(nodes, dev)
+    ul, _ = ops.evaluate(x, _t(W, dev), x[:-1].contiguous())
+    assert np.max(np.abs(ul.cpu().numpy()[1:] - values[1:-1])) < 1e-11    # u_e(x_e) = g_l (interior)
+    xc = ops.colloc_points(x, n)
+    f = _t(orc.poisson_rhs(xc.cpu().numpy()), dev)
+    W2, st2 = ops.enhance(x, _t(values, dev), M, 1e4, n, global_domain=gd, rhs_values=f)
+    torch.cuda.synchronize()
+    assert int(st2.sum()) == 0
+    et = orc.rel_l2_coef(W2.cpu().numpy(), W).max()
+    note("cold boundary rows M=%d |x|/h=%.0e in-kernel rhs vs tabulated" % (M, ratio), et, 1e-12)
+    assert et <= 1e-12, et
+    if cf.HAVE_MP:
+        sel = [0, 1, 63, 64, ne // 2, ne - 1]
+        tr = cf.truth_all(nodes, values, M, 1e4, n, orc.poisson_rhs, gd, sel)
+        err = orc.rel_l2_coef(W[sel], tr).max()
+        note("cold boundary rows M=%d |x|/h=%.0e vs 60-digit minimiser" % (M, ratio), err, TOL_TRUTH)
+        assert err <= TOL_TRUTH, err
+
+
+def test_lane_kernel_cold_path_is_per_wave(dev):
+    """One mesh, far from the origin on the left and near it on the right: some waves take the
+    exact boundary rows, others the first-order ones; both agree with the oracle and the switch
+    leaves no seam."""
+    M, n = 9, 16
+    left = 3.0e7 + 0.05 * np.arange(200)                       # |x|/h = 6e8: cold
+    right = left[-1] + np.cumsum(np.full(250, 8.0))            # |x|/h = 4e6: first order (gamma scl^4 = 39)
+    nodes = np.concatenate([left, right])
+    ne = len(nodes) - 1
+    values = np.cos(0.37 * np.arange(ne + 1))
+    gd = (nodes[0], nodes[-1])
+    _, slow_wave = _boundary_rows_slow(nodes, M)
+    assert slow_wave[:3].all() and not slow_wave[4:].any()
+    W, st = _enhance(dev, nodes, values, M, 1e4, n, global_domain=gd)
+    assert np.all(st == 0)
+    Wo = orc.enhance_all_vec(nodes, values, M, 1e4, n, global_domain=gd)
+    assert orc.rel_l2_coef(W, Wo).max() <= 1e-11
+    if cf.HAVE_MP:
+        sel = [0, 191, 192, 199, 200, 255, 256, ne - 1]
+        tr = cf.truth_all(nodes, values, M, 1e4, n, orc.poisson_rhs, gd, sel)
+        assert orc.rel_l2_coef(W[sel], tr).max() <= TOL_TRUTH
+
+
+@pytest.mark.parametrize("x0,h", [(1.0e9, 512.0), (-3.0e8, 1.0 / 12), (2.5e9, 0.7)])
+def test_in_kernel_sin_per_point_branch(dev, note, x0, h):
+    """|omega x| ~ 1e9 .. 8e9: numpy's argument rounding fl(pi x_k) differs from the carried
+    rotation angle by more than 1e-7, so the wave evaluates sin at every point (sin_tab on the
+    exactly rounded argument, Dual.py:11-12 / 43-44) instead of the rotation + first-order
+    correction.  (1e9, 512): boundary rows on the first-order path, per-point sin only;
+    (-3e8, 1/12) and (2.5e9, 0.7): both cold paths together.  Against the tabulated path (numpy's
+    own sin at the same abscissae) and the 60-digit minimiser."""
+    import torch
+    from hybrid_fem_lssvr_amd import ops
+    ne, M, n = 140, 9, 16
+    nodes = x0 + h * np.arange(ne + 1)
+    values = np.sin(np.pi * nodes)
+    gd = (nodes[0], nodes[-1])
+    # the kernel's predicate for the per-point branch, restated
+    a = nodes[:-1]
+    step = (nodes[1:] - a) / (n - 1)
+    k = np.arange(n - 1, dtype=np.float64)
+    xk = k[None, :] * step[:, None] + a[:, None]
+    delta = (np.pi * xk - (np.pi * a)[:, None]) - k[None, :] * (np.pi * step)[:, None]
+    assert (np.abs(delta).max(1) > 1.0e-7).any()
+    _, slow_wave = _boundary_rows_slow(nodes, M)
+    assert slow_wave.all() == (h < 100.0) and slow_wave.any() == (h < 100.0)
+    x, u = _t(nodes, dev), _t(values, dev)
+    W1, s1 = ops.enhance(x, u, M, 1e4, n, global_domain=gd)
+    xc = ops.colloc_points(x, n).cpu().numpy()
+    W2, s2 = ops.enhance(x, u, M, 1e4, n, global_domain=gd, rhs_values=_t(orc.poisson_rhs(xc), dev))
+    torch.cuda.synchronize()
+    assert int(s1.sum()) == 0 and int(s2.sum()) == 0
+    W1, W2 = W1.cpu().numpy(), W2.cpu().numpy()
+    d = orc.rel_l2_coef(W1, W2).max()
+    db = orc.rel_l2_bubble(W1, W2).max()
+    note("per-point sin x0=%.1e h=%g: in-kernel vs tabulated (whole / bubble)" % (x0, h), d)
+    note("per-point sin x0=%.1e h=%g: bubble" % (x0, h), db)
+    assert d <= 1e-13, d
+    assert db <= 1e-11, db
+    if cf.HAVE_MP:
+        sel = [0, 1, 64, ne - 1]
+        tr = cf.truth_all(nodes, values, M, 1e4, n, orc.poisson_rhs, gd, sel)
+        err = orc.rel_l2_coef(W1[sel], tr).max()
+        note("per-point sin x0=%.1e h=%g vs 60-digit minimiser" % (x0, h), err, TOL_TRUTH)
+        assert err <= TOL_TRUTH, err
