@@ -38,7 +38,9 @@ template <int M, int RHS, bool VC>
 constexpr int kSmallTilePerWave =
     (RHS == LSSVR_RHS_ARRAY && (VC ? 3 : 1) * kStageArr > 64 * M) ? (VC ? 3 : 1) * kStageArr : 64 * M;
 // (RHS == LSSVR_RHS_ARRAY_PM: point-major tables, read directly -- no staging area)
-constexpr int kPrefetch = 4;   // point-major tables: points fetched ahead of their use
+// point-major tables: points fetched ahead of their use (measured at config 5, same box: 2 -> 102-104 us,
+// 4 -> 101-109 us, 6 and 8 -> 149 us (256 registers); plain instead of non-temporal loads: no difference)
+constexpr int kPrefetch = 4;
 
 template <int M, int RHS, bool VC>
 __device__ __forceinline__ void enhance_small_body(const EnhanceArgs& p, const unsigned block,

@@ -16,8 +16,11 @@ run sq_b  --pmc SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_C
 run sq_c  --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA --kernel-trace --output-format csv -d $O/sq_c -- python3 scripts/prof_c5.py
 run fetch --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- python3 scripts/prof_c5.py
 run write --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- python3 scripts/prof_c5.py
+run fetch_em --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch_em -- python3 scripts/prof_c5.py 1000008 5 wide element
+run write_em --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write_em -- python3 scripts/prof_c5.py 1000008 5 wide element
+run sq_em --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/sq_em -- python3 scripts/prof_c5.py 1000008 5 wide element
 run tcc   --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $O/tcc -- python3 scripts/prof_c5.py
-python3 scripts/pmc_summary.py $O/sq_a $O/sq_b $O/sq_c $O/fetch $O/write $O/tcc > $O/pmc_summary.txt 2>&1
+python3 scripts/pmc_summary.py $O/sq_a $O/sq_b $O/sq_c $O/fetch $O/write $O/fetch_em $O/write_em $O/sq_em $O/tcc > $O/pmc_summary.txt 2>&1
 cp $O/stats/*/*kernel_stats.csv $O/bench_c5_kernel_stats.csv 2>/dev/null
-tail -n 80 $O/pmc_summary.txt
+grep -v "at::native" $O/pmc_summary.txt | tail -n 150
 python3 bench.py --config 5 > $O/bench_c5.json 2> $O/bench_c5.err; echo "bench c5 rc=$?"

@@ -9,7 +9,7 @@ for d in sys.argv[1:]:
         for r in csv.DictReader(open(f)):
             dur[r["Kernel_Name"][:70]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     for k, v in dur.items():
-        if "lssvr" in k or "probe" in k or "kernel" in k:
+        if "lssvr" in k or "probe" in k:
             print(f"  {k}: n={len(v)} mean {sum(v)/len(v)/1e3:.1f} us min {min(v)/1e3:.1f} us")
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in cc:

@@ -48,3 +48,30 @@ def test_other_bench_lines_are_consistent(name):
     r = j["roofline"]
     assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-12 and 0.0 < r["frac"] < 1.5
     assert j["n_gpus"] == 1 and j["steps"] >= 1 and j["unit"] == "elements/s"
+
+
+def test_config5_bench_line_contract():
+    """BASELINE config 5 (`bench.py --config 5`): an HBM-bound line -- achieved = algorithmic bytes per launch /
+    the kernel's average launch duration, both roofs reported, accuracy against the 60-digit minimiser, the SLSQP
+    baseline with the variable-coefficient residual, PMC traffic from profiles/traffic.json."""
+    j = _line("r03_bench_c5.json")
+    assert j["unit"] == "elements/s" and j["n_gpus"] == 1 and j["dtype"] == "f64" and j["vs_baseline"] is None
+    assert "variable-coefficient" in j["metric"] and "workload" in j["config"]
+    ne = j["config"]["elements_total"]
+    assert ne in (1000008, 1000000)
+    assert abs(j["value"] - ne / (j["ms_per_step"] * 1e-3)) <= 1e-6 * j["value"]
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["bytes_per_element"] == 472
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-12 and 0.0 < r["frac"] <= 1.0
+    assert abs(r["achieved"] - 472 * r["elements_per_launch"] / (r["kernel_us_avg"] * 1e-6) / 1e9) <= 1e-9 * r["achieved"]
+    assert r["kernel_us_avg"] * 1e-3 <= 1.05 * j["ms_per_step"]
+    f = j["roofline_fp64"]
+    assert abs(f["frac"] - f["achieved"] / f["peak"]) <= 1e-12 and 0.0 < f["frac"] <= 1.0
+    assert j["accuracy"]["rel_l2_vs_60_digit_minimiser"] <= 1e-13
+    assert j["accuracy"]["rel_l2_bubble_vs_60_digit_minimiser"] <= 1e-13
+    c = j["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "Dual.py:43-44" in c["sample"]
+    assert j["other_table_layout"]["W_bit_equal_to_primary_layout"] is True
+    assert j["value"] >= 1.0e6
+    t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["c5_M9_n16_ne1000008"]
+    assert 0.9 <= t["hbm_bytes_per_launch"] / t["algorithmic_bytes_per_launch"] <= 1.25
