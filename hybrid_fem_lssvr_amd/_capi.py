@@ -75,6 +75,11 @@ SIGNATURES = {
                                       _c_int, _c_int, _c_dbl, _c_dp,
                                       _c_int, C.POINTER(_c_dbl), _c_dp,
                                       _c_dp, _c_i64, _c_dp, _c_dp, _c_dp]),
+    "lssvr_enhance_subset_ws": (_c_int, [_c_dp, _c_dp, _c_i64, _c_dp, _c_i64, _c_i64, _c_i64,
+                                         _c_dbl, _c_dbl, _c_dbl, _c_dbl,
+                                         _c_int, _c_int, _c_dbl, _c_dp,
+                                         _c_int, C.POINTER(_c_dbl), _c_dp,
+                                         _c_dp, _c_i64, _c_dp, _c_dp, _c_dp, _c_i64, _c_dp]),
     "lssvr_enhance_shared": (_c_int, [_c_dp, _c_dp, _c_i64, _c_i64, _c_i64,
                                       _c_dbl, _c_dbl, _c_dbl, _c_dbl,
                                       _c_int, _c_int,

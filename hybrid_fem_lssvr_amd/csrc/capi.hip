@@ -105,7 +105,7 @@ int enhance_dispatch(const lssvr::EnhanceArgs& a, int solver_id, hipStream_t s,
     return fail(LSSVR_ERR_SOLVER, "subset launches take LSSVR_SOLVER_PRIMAL");
   // large degree, Poisson rows, workspace given: Chebyshev moments + four-systems-per-wave solve as
   // two kernels (twice the speed of the MFMA kernel)
-  if (solver_id == LSSVR_SOLVER_PRIMAL && !a.a_values && !a.elem_ids && work &&
+  if (solver_id == LSSVR_SOLVER_PRIMAL && !a.a_values && work &&
       work_bytes >= lssvr::enhance_moment_ws_bytes(a.ne, a.M, a.n))
     return check_launch(lssvr::enhance_large_split(a, work, s, o), "enhance_large_split");
   // LSSVR_SOLVER_PRIMAL_MOMENT forces that sequence for any M (A/B against the lane kernel below M = 23)
@@ -323,6 +323,18 @@ int lssvr_enhance_subset(const double* x, const double* u, int64_t ne_mesh,
                          const double* gamma_values, int rhs_id, const double* rhs_params_host,
                          const double* rhs_values, double* W, int64_t ldw, int32_t* status,
                          int32_t* fail_count, void* stream) {
+  return lssvr_enhance_subset_ws(x, u, ne_mesh, elem_ids, nsub, elem_offset, ne_global, gxmin, gxmax, bc_left,
+                                 bc_right, M, n_colloc, gamma, gamma_values, rhs_id, rhs_params_host, rhs_values,
+                                 W, ldw, status, fail_count, nullptr, 0, stream);
+}
+
+int lssvr_enhance_subset_ws(const double* x, const double* u, int64_t ne_mesh,
+                            const int64_t* elem_ids, int64_t nsub, int64_t elem_offset,
+                            int64_t ne_global, double gxmin, double gxmax, double bc_left,
+                            double bc_right, int M, int n_colloc, double gamma,
+                            const double* gamma_values, int rhs_id, const double* rhs_params_host,
+                            const double* rhs_values, double* W, int64_t ldw, int32_t* status,
+                            int32_t* fail_count, void* work, int64_t work_bytes, void* stream) {
   if (ne_mesh < 0 || nsub < 0) return fail(LSSVR_ERR_SIZE, "ne_mesh / nsub < 0");
   if (!elem_ids && nsub != ne_mesh)
     return fail(LSSVR_ERR_SIZE, "elem_ids == NULL means every element: nsub must equal ne_mesh");
@@ -350,10 +362,14 @@ int lssvr_enhance_subset(const double* x, const double* u, int64_t ne_mesh,
   if (rc != LSSVR_OK) return rc;
   a.status = status;
   a.fail_count = fail_count;
+  if (work_bytes < 0 || (work_bytes > 0 && !work)) return fail(LSSVR_ERR_NULL, "work / work_bytes inconsistent");
+  const int64_t need = lssvr_enhance_work_bytes(nsub, M, n_colloc, LSSVR_SOLVER_PRIMAL);
+  if (work && work_bytes < need)
+    return fail(LSSVR_ERR_SIZE, "work holds %lld bytes, lssvr_enhance_work_bytes(nsub = %lld, %d, %d, 0) = %lld",
+                (long long)work_bytes, (long long)nsub, M, n_colloc, (long long)need);
   if (nsub == 0) return LSSVR_OK;
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (M <= lssvr::kSmallMaxM) return check_launch(lssvr::enhance_small(a, s), "enhance_small(subset)");
-  return check_launch(lssvr::enhance_large(a, s), "enhance_large(subset)");
+  // (M <= 22: the lane kernel; above, with a workspace: moments + solve kernels, without: the MFMA kernel)
+  return enhance_dispatch(a, LSSVR_SOLVER_PRIMAL, reinterpret_cast<hipStream_t>(stream), nullptr, work, work_bytes);
 }
 
 int lssvr_enhance_shared(const double* x, const double* u, int64_t ne, int64_t elem_offset,

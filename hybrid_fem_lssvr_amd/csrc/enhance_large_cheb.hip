@@ -506,7 +506,11 @@ __global__ __launch_bounds__(256) void residual_kernel(EnhanceArgs p, double* __
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const bool live = e < p.ne;
   const int64_t ec = live ? e : p.ne - 1;
-  const int64_t id = ec;                       // (no subset form of the two-kernel path)
+  int64_t id = ec;                             // position in the launch -> mesh index
+  if (p.elem_ids) {
+    id = p.elem_ids[ec];
+    if (id < 0 || id >= p.ne_mesh) id = 0;     // (skipped by the solve kernel)
+  }
   const int n = p.n;
   const double a = p.x[id];
   const double b = p.x[id + 1];
@@ -594,7 +598,7 @@ int64_t enhance_moment_ws_bytes(int64_t ne, int M, int n) {
 }
 
 hipError_t enhance_large_split(const EnhanceArgs& a, void* work, hipStream_t s, const LaunchOpts* o) {
-  if (a.M - 2 + 1 > kLP || a.a_values || a.elem_ids || !work) return hipErrorInvalidValue;
+  if (a.M - 2 + 1 > kLP || a.a_values || !work) return hipErrorInvalidValue;
   double* const ws = static_cast<double*>(work);
   double* const zws = ws + a.ne * kWsStride;
   const int steps = enhance_refine_steps(a.M, a.n);

@@ -170,8 +170,16 @@ __global__ __launch_bounds__(64 * kWaves, 2) void solve4_parity_kernel(EnhanceAr
     if (quad < nquads) fetch(quad);
 
     const int64_t e_raw = E0 + g;
-    const bool live = e_raw < p.ne;
-    const int64_t id = live ? e_raw : p.ne - 1;
+    bool live = e_raw < p.ne;
+    int64_t id = live ? e_raw : p.ne - 1;              // position in the launch ...
+    if (p.elem_ids) {                                   // ... -> mesh index (lssvr_enhance_subset_ws)
+      id = p.elem_ids[id];
+      if (id < 0 || id >= p.ne_mesh) {       // out-of-range id: nothing of the mesh is touched
+        if (live && q == 0 && p.fail_count) atomicAdd(p.fail_count, 1);
+        live = false;
+        id = 0;
+      }
+    }
     const double a = el[121], b = el[122], gl = el[123], gr = el[155];
     const double inv_gamma = p.gamma_values ? rcp_newton(p.gamma_values[id]) : p.inv_gamma;
     const DomainMap dm = map_params(a, b);
@@ -376,7 +384,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void solve4_parity_kernel(EnhanceAr
 bool enhance_parity_applies(int M, int n) { return M > kSmallMaxM && M <= kLargeMaxM && n >= 2 * (M - 2); }
 
 hipError_t launch_solve4_parity(const EnhanceArgs& a, const double* ws, hipStream_t s, hipEvent_t ev_stop) {
-  if (a.a_values || a.elem_ids || !ws) return hipErrorInvalidValue;
+  if (a.a_values || !ws) return hipErrorInvalidValue;
   int64_t blocks = (a.ne + 4 * kWaves - 1) / (4 * kWaves);
   const int64_t resident = (int64_t)cu_count() * kResidentPerCu;       // persistent: one resident set
   if (blocks > resident) blocks = resident;

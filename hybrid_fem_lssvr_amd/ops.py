@@ -177,11 +177,13 @@ def enhance(x, u, M, gamma, n_colloc=12, *, rhs=(POISSON_AMP, POISSON_OMEGA), rh
 def enhance_subset(x, u, M, gamma, n_colloc, W, *, elem_ids=None, gamma_values=None,
                    rhs=(POISSON_AMP, POISSON_OMEGA), rhs_values=None, elem_offset=0, ne_global=None,
                    global_domain, bc=(0.0, 0.0), status=None, fail_count=None, stream=None,
-                   point_major=False):
-    """``lssvr_enhance_subset``: the elements ``elem_ids`` (int64 device tensor of mesh indices;
+                   point_major=False, work=None):
+    """``lssvr_enhance_subset_ws``: the elements ``elem_ids`` (int64 device tensor of mesh indices;
     None = all) of the shard (x, u) with one (M, n_colloc); per-element ``gamma_values``
     (float64[ne], indexed by mesh element) optional.  Rows go to ``W[id, :M]`` of the caller's
-    float64[ne, ldw] array (ldw = W.shape[1] >= M; zero it first when ldw > M)."""
+    float64[ne, ldw] array (ldw = W.shape[1] >= M; zero it first when ldw > M).  ``work``: as in
+    :func:`enhance` (above M = 22 the group runs as the moment / solve kernel pair; ``False``: the
+    single f64-MFMA kernel)."""
     lib = _capi.load()
     _dev(x, "x")
     _dev(u, "u")
@@ -213,13 +215,19 @@ def enhance_subset(x, u, M, gamma, n_colloc, W, *, elem_ids=None, gamma_values=N
         rhs_id, params = (RHS_ARRAY_PM if point_major else RHS_ARRAY), None
     else:
         rhs_id, params = RHS_SIN, _capi.rhs_params(*rhs)
-    rc = lib.lssvr_enhance_subset(_ptr(x), _ptr(u), ne, _ptr(elem_ids), int(nsub), int(elem_offset),
-                                  int(ne_global), float(global_domain[0]), float(global_domain[1]),
-                                  float(bc[0]), float(bc[1]), int(M), int(n_colloc), float(gamma),
-                                  _ptr(gamma_values), rhs_id, params, _ptr(rhs_values),
-                                  _ptr(W), int(W.shape[1]), _ptr(status), _ptr(fail_count),
-                                  _stream(stream))
-    _capi.check(rc, "lssvr_enhance_subset")
+    if work is None:
+        work = workspace(lib, x.device, nsub, M, n_colloc, SOLVER_PRIMAL, stream)
+    elif work is False:
+        work = None
+    else:
+        _dev(work, "work")
+    rc = lib.lssvr_enhance_subset_ws(_ptr(x), _ptr(u), ne, _ptr(elem_ids), int(nsub), int(elem_offset),
+                                     int(ne_global), float(global_domain[0]), float(global_domain[1]),
+                                     float(bc[0]), float(bc[1]), int(M), int(n_colloc), float(gamma),
+                                     _ptr(gamma_values), rhs_id, params, _ptr(rhs_values),
+                                     _ptr(W), int(W.shape[1]), _ptr(status), _ptr(fail_count),
+                                     _ptr(work), 0 if work is None else work.numel() * 8, _stream(stream))
+    _capi.check(rc, "lssvr_enhance_subset_ws")
     return W
 
 

@@ -241,6 +241,23 @@ int lssvr_enhance_subset(const double* x, const double* u, int64_t ne_mesh,
                          void* stream);
 
 /*
+ * lssvr_enhance_subset_ws -- lssvr_enhance_subset with a caller workspace (ABI 4): above M = 22 the
+ * group then runs as the moment / solve kernel pair of lssvr_enhance_ws (twice the speed of the
+ * single f64-MFMA kernel, and the near-square refinement) -- rows, status and gamma_values by mesh
+ * index, tables and the workspace by position in elem_ids.
+ *   work / work_bytes   lssvr_enhance_work_bytes(nsub, M, n_colloc, LSSVR_SOLVER_PRIMAL) bytes of device
+ *                       scratch (0 below M = 23); NULL: as lssvr_enhance_subset; too small: LSSVR_ERR_SIZE
+ */
+int lssvr_enhance_subset_ws(const double* x, const double* u, int64_t ne_mesh,
+                            const int64_t* elem_ids, int64_t nsub,
+                            int64_t elem_offset, int64_t ne_global,
+                            double gxmin, double gxmax, double bc_left, double bc_right,
+                            int M, int n_colloc, double gamma, const double* gamma_values,
+                            int rhs_id, const double* rhs_params_host, const double* rhs_values,
+                            double* W, int64_t ldw, int32_t* status, int32_t* fail_count,
+                            void* work, int64_t work_bytes, void* stream);
+
+/*
  * lssvr_enhance_shared -- UNIFORM meshes only; a separate, faster form of the hot path, never
  * chosen implicitly.  On a uniform mesh every element has the same system matrix, so the
  * coefficients are a linear map of the element's data:

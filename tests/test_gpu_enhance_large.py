@@ -210,11 +210,15 @@ def test_workspace_free_entry_matches_two_kernel_path(dev, golden):
     assert torch.equal(W2, W3)
     bands = orc.p1_scatter(*orc.p1_assemble_local(nodes))
     assert np.allclose(plan.bands["diag"].cpu().numpy(), bands[0], rtol=1e-15)
-    # a workspace that is too small falls back to the workspace-free kernel instead of overrunning it
+    # a workspace that is given but too small is an error (ABI 4; ABI 3 silently ran the workspace-free
+    # kernel, whose accuracy differs in the near-square regime): nothing is launched, W stays as it is
+    from hybrid_fem_lssvr_amd import _capi
     small = torch.empty(16, dtype=torch.float64, device=dev)
-    W4, _ = ops.enhance(x, u, M, gamma, n, global_domain=(-1.0, 1.0), work=small)
+    W4 = torch.full((len(nodes) - 1, M), 7.0, dtype=torch.float64, device=dev)
+    with pytest.raises(_capi.LssvrHipError, match="lssvr_enhance_work_bytes"):
+        ops.enhance(x, u, M, gamma, n, global_domain=(-1.0, 1.0), work=small, out=W4)
     torch.cuda.synchronize()
-    assert torch.equal(W4, W1)
+    assert bool((W4 == 7.0).all())
 
 
 # (M, n, h, bar of the refined two-kernel path, floor of the unrefined single kernel): numbers of

@@ -75,19 +75,24 @@ def test_subset_leaves_other_rows_alone(dev):
         W = torch.full((130, M + 3), 7.0, dtype=torch.float64, device=dev)
         st = torch.full((130,), -5, dtype=torch.int32, device=dev)
         ids = torch.as_tensor(np.array([129, 0, 64, 3, 77], dtype=np.int64), device=dev)
-        ops.enhance_subset(x, u, M, 1e4, n, W, elem_ids=ids, global_domain=gd, status=st)
-        torch.cuda.synchronize()
-        Wh, sth = W.cpu().numpy(), st.cpu().numpy()
         touched = np.zeros(130, dtype=bool)
         touched[[129, 0, 64, 3, 77]] = True
-        assert np.all(Wh[~touched] == 7.0) and np.all(sth[~touched] == -5)
-        assert np.all(Wh[touched][:, M:] == 7.0) and np.all(sth[touched] == 0)
-        # (a subset launch runs the workspace-free kernels: bit-identical to `work=False`, and
-        # within rounding of the two-kernel default above M = 22)
         Wfull, _ = ops.enhance(x, u, M, 1e4, n, global_domain=gd, work=False)
-        assert np.array_equal(Wh[touched][:, :M], Wfull.cpu().numpy()[touched])
         Wdef, _ = ops.enhance(x, u, M, 1e4, n, global_domain=gd)
-        assert orc.rel_l2_coef(Wh[touched][:, :M], Wdef.cpu().numpy()[touched]).max() <= 1e-12
+        # work=False: the workspace-free kernels, bit-identical to the full launch with work=False;
+        # default: above M = 22 the moment / solve pair (ABI 4), within rounding of both
+        for work in (False, None):
+            W.fill_(7.0)
+            st.fill_(-5)
+            ops.enhance_subset(x, u, M, 1e4, n, W, elem_ids=ids, global_domain=gd, status=st, work=work)
+            torch.cuda.synchronize()
+            Wh, sth = W.cpu().numpy(), st.cpu().numpy()
+            assert np.all(Wh[~touched] == 7.0) and np.all(sth[~touched] == -5)
+            assert np.all(Wh[touched][:, M:] == 7.0) and np.all(sth[touched] == 0)
+            if work is False:
+                assert np.array_equal(Wh[touched][:, :M], Wfull.cpu().numpy()[touched])
+            assert orc.rel_l2_coef(Wh[touched][:, :M], Wdef.cpu().numpy()[touched]).max() <= 1e-12
+            assert orc.rel_l2_coef(Wh[touched][:, :M], Wfull.cpu().numpy()[touched]).max() <= 1e-12
 
 
 def test_subset_argument_errors(dev):
@@ -107,7 +112,8 @@ def test_subset_argument_errors(dev):
 def test_subset_out_of_range_ids_touch_nothing(dev):
     """An id outside [0, ne_mesh) must not become an out-of-bounds access: the element is
     skipped (no load, no store) and counted in fail_count; valid ids of the same launch are
-    enhanced as usual (both kernels: lane mapping M = 9, wave mapping M = 33)."""
+    enhanced as usual (lane kernel M = 9; moment + parity-split solve kernels M = 33; the f64-MFMA kernel's
+    range check is covered by test_large_degree_subset_runs_the_two_kernel_path)."""
     import torch
     from hybrid_fem_lssvr_amd import ops
     _, nodes, values = _mesh(90, 15)
@@ -129,5 +135,56 @@ def test_subset_out_of_range_ids_touch_nothing(dev):
         good[[6, 18, 90]] = True
         assert np.all(Wh[~good] == 7.0) and np.all(sth[~good] == -5)
         assert np.all(sth[good] == 0)
-        Wfull, _ = ops.enhance(x, u, M, 1e4, n, global_domain=gd, work=False)
+        # (the default subset launch above M = 22 is the moment / solve pair, like the default full launch)
+        Wfull, _ = ops.enhance(x, u, M, 1e4, n, global_domain=gd)
         assert np.array_equal(Wh[good], Wfull.cpu().numpy()[[5, 17, 89]])
+
+
+@pytest.mark.parametrize("M,n", [(33, 64), (33, 40), (33, 31), (24, 44), (27, 27)])
+def test_large_degree_subset_runs_the_two_kernel_path(dev, M, n):
+    """lssvr_enhance_subset_ws (ABI 4): above M = 22 a subset group runs as moments + solve kernels --
+    the parity-split solve (n >= 2 (M-2)), the full four-systems-per-wave solve, and the refined
+    near-square regime -- with rows / status / gamma by mesh index and the workspace by position.
+    Against the single f64-MFMA kernel (work=False), the float64 oracle of each element's own problem
+    and, in the refined regime, the 60-digit minimiser (where the MFMA kernel is 1e-6 .. 1e-10 off)."""
+    import torch
+    from hybrid_fem_lssvr_amd import ops
+    from oracle import closed_form_mp as cf
+    rng, nodes, values = _mesh(150, 40 + M + n)
+    ne = 150
+    gd = (nodes[0], nodes[-1])
+    x, u = torch.as_tensor(nodes, device=dev), torch.as_tensor(values, device=dev)
+    ids_h = np.concatenate([rng.permutation(ne)[:61], [ne + 5, -1]]).astype(np.int64)     # two ids out of range
+    ids = torch.as_tensor(ids_h, device=dev)
+    gam_h = 10.0 ** rng.uniform(3, 5, ne)
+    gam = torch.as_tensor(gam_h, device=dev)
+    out = {}
+    for tag, work in (("split", None), ("mfma", False)):
+        W = torch.full((ne, M + 2), 7.0, dtype=torch.float64, device=dev)
+        st = torch.full((ne,), -5, dtype=torch.int32, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+        ops.enhance_subset(x, u, M, 1.0, n, W, elem_ids=ids, gamma_values=gam, global_domain=gd, status=st,
+                           fail_count=cnt, work=work)
+        torch.cuda.synchronize()
+        out[tag] = (W.cpu().numpy(), st.cpu().numpy(), int(cnt.item()))
+    good = ids_h[:-2]
+    for tag in out:
+        W, st, cnt = out[tag]
+        assert cnt == 2                                             # the two out-of-range ids, nothing else
+        assert np.all(st[good] == 0)
+        rest = np.setdiff1d(np.arange(ne), good)
+        assert np.all(W[rest] == 7.0) and np.all(st[rest] == -5)    # untouched rows stay untouched
+        assert np.all(W[good][:, M:] == 7.0)                        # ... and so do the pad columns (ldw = M + 2)
+    near_square = n - (M - 2) <= 14
+    agree = orc.rel_l2_coef(out["split"][0][good][:, :M], out["mfma"][0][good][:, :M]).max()
+    assert agree <= (1e-4 if near_square else 1e-12), agree
+    sel = good[:4]
+    if near_square and cf.HAVE_MP:
+        tr = np.array([cf.solve_truth(orc.element_system(
+            nodes[i], nodes[i + 1], *orc.boundary_values(int(i), ne, nodes[i], nodes[i + 1], values[i], values[i + 1], gd),
+            M, gam_h[i], n)) for i in sel])
+        assert orc.rel_l2_coef(out["split"][0][sel][:, :M], tr).max() <= 2e-12
+    else:
+        for i in sel:
+            wo = _oracle_element(nodes, values, int(i), M, gam_h[i], n, gd)
+            assert orc.rel_l2_coef(out["split"][0][i, :M][None], wo[None]).max() <= 1e-11
