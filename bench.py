@@ -98,9 +98,29 @@ def self_launch(n, argv):
                    LSSVR_BENCH_SELF_LAUNCHED="1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=(None if r == 0 else subprocess.DEVNULL)))
+    # poll all ranks: the first non-zero exit ends the others (a rank that died would otherwise leave
+    # its siblings blocked in a collective, holding their GPUs until the RCCL timeout)
     rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            r = p.poll()
+            if r is None:
+                continue
+            live.remove(p)
+            if r != 0:
+                rc = max(rc, abs(r))
+                for q in live:
+                    q.terminate()
+                deadline = time.time() + 10.0
+                for q in live:
+                    try:
+                        q.wait(timeout=max(0.1, deadline - time.time()))
+                    except subprocess.TimeoutExpired:
+                        q.kill()
+                live = []
+                break
     return rc
 
 
@@ -246,6 +266,11 @@ class Dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    def all_ok(self, ok):
+        """True iff EVERY rank passes True: ranks agree on a failure before any of them enters the
+        collectives of a timed region (a rank that raised on its own would leave the others blocked)."""
+        return self.max(0.0 if ok else 1.0) == 0.0
+
 
 def timed_compute(wl, D, steps, warmup):
     """K launches of the fused step on the current stream between two HIP events; barrier +
@@ -272,31 +297,38 @@ def timed_compute(wl, D, steps, warmup):
     return D.max(dev_s), D.max(wall)
 
 
-def timed_stitch(wl, D, steps, warmup, what, algo):
+def timed_stitch(wl, D, steps, warmup, what, algo, samples=SAMPLES_PER_ELEMENT):
     """The stitched step, K times: step i computes into buffer i%2 on the main stream (and, for
-    what == "u", evaluates the shard's solution at SAMPLES_PER_ELEMENT points per element,
-    rank-local), then its all-gather runs on a side stream while step i+1 computes into the
-    other buffer.  Event-bracketed like timed_compute; the closing event waits for the last
-    gather.  Returns dict(seconds, bytes, intact)."""
+    what == "u", evaluates the shard's solution at ``samples`` points per element, rank-local),
+    then its all-gather runs on a side stream while step i+1 computes into the other buffer.
+    Event-bracketed like timed_compute; the closing event waits for the last gather.
+    Buffers are allocated first and the ranks AGREE that all of them succeeded before anyone enters
+    a collective (RuntimeError on every rank otherwise).  Returns dict(seconds, bytes, intact)."""
     import torch
     from hybrid_fem_lssvr_amd import ops
-    from hybrid_fem_lssvr_amd.distributed import allgather_flat
+    from hybrid_fem_lssvr_amd.distributed import allgather_flat, stitch_traffic_model
     dev, world, rank = wl.dev, wl.world, wl.rank
     pad = wl.plan.max_size
     main = torch.cuda.current_stream(dev)
-    comm = torch.cuda.Stream(device=dev)
-    if what == "u":
-        h_el = wl.x[1:] - wl.x[:-1]
-        fr = [(2 * k + 1) / (2.0 * SAMPLES_PER_ELEMENT) for k in range(SAMPLES_PER_ELEMENT)]
-        xq = torch.stack([wl.x[:-1] + f * h_el for f in fr], dim=1).reshape(-1).contiguous()
-        width = SAMPLES_PER_ELEMENT
-    else:
-        xq = None
-        width = wl.M
-    # padded send buffers (equal on every rank), gathered rank-major
-    send = (wl.Wflat if what == "W" else
-            [torch.zeros(pad * width, dtype=torch.float64, device=dev) for _ in range(2)])
-    recv = [torch.empty(world * pad * width, dtype=torch.float64, device=dev) for _ in range(2)]
+    width = samples if what == "u" else wl.M
+    setup_error = None
+    try:
+        comm = torch.cuda.Stream(device=dev)
+        if what == "u":
+            h_el = wl.x[1:] - wl.x[:-1]
+            fr = [(2 * k + 1) / (2.0 * samples) for k in range(samples)]
+            xq = torch.stack([wl.x[:-1] + f * h_el for f in fr], dim=1).reshape(-1).contiguous()
+        else:
+            xq = None
+        # padded send buffers (equal on every rank), gathered rank-major
+        send = (wl.Wflat if what == "W" else
+                [torch.zeros(pad * width, dtype=torch.float64, device=dev) for _ in range(2)])
+        recv = [torch.empty(world * pad * width, dtype=torch.float64, device=dev) for _ in range(2)]
+    except Exception as exc:  # pragma: no cover  (out of memory on one rank)
+        setup_error = exc
+    if not D.all_ok(setup_error is None):
+        raise RuntimeError("stitch %s/%s: buffer setup failed on at least one rank (%r here)"
+                           % (what, algo, setup_error))
     n_own = wl.ne_loc * width
     done = [None, None]
 
@@ -332,38 +364,44 @@ def timed_stitch(wl, D, steps, warmup, what, algo):
     kk = (steps - 1) & 1
     own = recv[kk][rank * pad * width: rank * pad * width + n_own]
     intact = bool(torch.equal(own, send[kk][:n_own]))
+    model = stitch_traffic_model(wl.ne_glob, world, 8 * width)
     return {"seconds": sec, "bytes_received_per_rank_per_step": (world - 1) * pad * width * 8,
-            "own_block_intact": intact, "bytes_per_element": 8 * width}
+            "own_block_intact": intact, "bytes_per_element": 8 * width,
+            "model": {"bytes_received_per_rank_per_step": model["bytes_received_per_rank_per_step"],
+                      "xgmi_floor_ms_direct_all_pairs": model["direct_all_pairs_floor_s"] * 1e3,
+                      "xgmi_floor_ms_ring": model["ring_floor_s"] * 1e3}}
 
 
-def measure_multi(wl, D, steps, warmup, algos):
-    """Compute-only region + both stitches with every all-gather algorithm."""
+def measure_multi(wl, D, steps, warmup, algos, samples_list=(2, 1)):
+    """Compute-only region + the stitches with every all-gather algorithm: u at every sample count of
+    ``samples_list`` (the first one is the headline ``stitch_u``), then W.  A failure inside a timed
+    collective region is NOT caught per rank (the others would block in the collective): it ends the
+    job, and bench.py's self-launcher / torchrun ends the sibling ranks."""
     dev_s, wall_s = timed_compute(wl, D, steps, warmup)
     total = wl.ne_glob * steps
     res = {"elements_total": wl.ne_glob, "elements_per_rank": wl.plan.max_size,
            "value": total / dev_s, "ms_per_step": dev_s / steps * 1e3,
            "host_wall_ms_per_step": wall_s / steps * 1e3}
-    for what in ("u", "W"):
+    jobs = [("u", sp) for sp in samples_list] + [("W", None)]
+    for what, sp in jobs:
         by_algo = {}
         for algo in algos:
-            try:
-                r = timed_stitch(wl, D, steps, warmup, what, algo)
-                r["value_with_allgather"] = total / r["seconds"]
-                r["ms_per_step"] = r.pop("seconds") / steps * 1e3
-                r["recv_GBps_per_rank"] = r["bytes_received_per_rank_per_step"] / (r["ms_per_step"] * 1e-3) / 1e9
-                by_algo[algo] = r
-            except Exception as exc:  # pragma: no cover
-                by_algo[algo] = {"error": repr(exc)}
-        good = {a: r for a, r in by_algo.items() if "error" not in r}
-        best = max(good, key=lambda a: good[a]["value_with_allgather"]) if good else None
-        res["stitch_" + what] = {
-            "what": ("rank-local lssvr_eval at %d points per element + all-gather of u (%d B per element)"
-                     % (SAMPLES_PER_ELEMENT, 8 * SAMPLES_PER_ELEMENT)) if what == "u" else
+            r = timed_stitch(wl, D, steps, warmup, what, algo, **({"samples": sp} if sp else {}))
+            r["value_with_allgather"] = total / r["seconds"]
+            r["ms_per_step"] = r.pop("seconds") / steps * 1e3
+            r["recv_GBps_per_rank"] = r["bytes_received_per_rank_per_step"] / (r["ms_per_step"] * 1e-3) / 1e9
+            by_algo[algo] = r
+        best = max(by_algo, key=lambda a: by_algo[a]["value_with_allgather"]) if by_algo else None
+        key = "stitch_W" if what == "W" else ("stitch_u" if sp == samples_list[0] else "stitch_u_%d_sample" % sp)
+        res[key] = {
+            "what": ("rank-local lssvr_eval at %d point%s per element + all-gather of u (%d B per element)"
+                     % (sp, "" if sp == 1 else "s", 8 * sp)) if what == "u" else
                     "all-gather of the coefficient rows W (%d B per element)" % (8 * wl.M),
+            "samples_per_element": sp,
             "overlap": "gather of step i on a side stream under the kernels of step i+1 (double-buffered)",
             "algorithms": by_algo, "picked": best,
-            "value_with_allgather": good[best]["value_with_allgather"] if best else None,
-            "ms_per_step": good[best]["ms_per_step"] if best else None,
+            "value_with_allgather": by_algo[best]["value_with_allgather"] if best else None,
+            "ms_per_step": by_algo[best]["ms_per_step"] if best else None,
         }
     return res
 
@@ -517,8 +555,9 @@ def run_multi(args, D, M, n, ne_glob, lo, hi, rank, world, dev, backend):
     import torch.distributed as dist
     from hybrid_fem_lssvr_amd.distributed import ALLGATHER_ALGOS
     algos = [] if args.no_gather else list(ALLGATHER_ALGOS)
+    samples_list = (2, 1) if args.stitch_samples == 0 else (args.stitch_samples,)
     wl = Workload(ne_glob, lo, hi, M, n, rank, world, dev, nbuf=2)
-    res = measure_multi(wl, D, args.steps, args.warmup, algos)
+    res = measure_multi(wl, D, args.steps, args.warmup, algos, samples_list)
     n_fallback = D.max(float(wl.status.sum().item()))
 
     # the other scaling mode, shorter (same code path, other sizes)
@@ -532,7 +571,7 @@ def run_multi(args, D, M, n, ne_glob, lo, hi, rank, world, dev, backend):
             half2 = ne2 / 24.0
             l2, h2 = (-half2, half2) if args.domain == "wide" else (lo, hi)
             wl2 = Workload(ne2, l2, h2, M, n, rank, world, dev, nbuf=2)
-            r2 = measure_multi(wl2, D, max(args.steps // 2, 5), min(args.warmup, 5), algos)
+            r2 = measure_multi(wl2, D, max(args.steps // 2, 5), min(args.warmup, 5), algos, samples_list[:1])
             second = (lbl, {"workload": wl2.describe(args.degree), "value": r2["value"],
                             "ms_per_step": r2["ms_per_step"],
                             "value_with_allgather": (r2.get("stitch_u") or {}).get("value_with_allgather"),
@@ -557,6 +596,20 @@ def run_multi(args, D, M, n, ne_glob, lo, hi, rank, world, dev, backend):
         except Exception as exc:  # pragma: no cover
             one_rank = {"error": repr(exc)}
 
+    # one rank alone on ITS share of the job (the per-rank size): the denominator of the scaling efficiency
+    per_rank = None
+    try:
+        if rank == 0:
+            wr = Workload(wl.plan.max_size, lo, lo + (hi - lo) * wl.plan.max_size / ne_glob, M, n, 0, 1, dev)
+            k3 = max(args.steps // 2, 5)
+            dr, _ = timed_compute(wr, Dist(False, backend, dev), k3, 3)
+            per_rank = {"what": "%d elements (one rank's share) on rank 0 alone, compute only" % wl.plan.max_size,
+                        "value": wl.plan.max_size * k3 / dr, "ms_per_step": dr / k3 * 1e3}
+            del wr
+        D.barrier()
+    except Exception as exc:  # pragma: no cover
+        per_rank = {"error": repr(exc)}
+
     if rank != 0:
         return None
     su = res.get("stitch_u") or {}
@@ -569,7 +622,7 @@ def run_multi(args, D, M, n, ne_glob, lo, hi, rank, world, dev, backend):
             "timed region; SURVEY.md 8(d)); value_with_allgather = the whole stitched step (kernel + rank-local "
             "evaluation of u at %d points per element + all-gather of u over xGMI, gather of step i under the "
             "kernel of step i+1). BASELINE's '>= 6x at 8 GPUs' is judged on value_with_allgather: config 3 "
-            "names the all-gather of u as part of the 8-GPU job." % SAMPLES_PER_ELEMENT),
+            "names the all-gather of u as part of the 8-GPU job." % samples_list[0]),
         "unit": "elements/s",
         "n_gpus": world,
         "ranks_in_process_group": dist.get_world_size(),
@@ -597,6 +650,20 @@ def run_multi(args, D, M, n, ne_glob, lo, hi, rank, world, dev, backend):
         "stitch_u": res.get("stitch_u"),
         "stitch_W": res.get("stitch_W"),
     }
+    for key in res:
+        if key.startswith("stitch_u_"):
+            out[key] = res[key]
+    if per_rank is not None:
+        out["one_rank_per_rank_size"] = per_rank
+        if "value" in per_rank:
+            ideal = world * per_rank["value"]
+            out["scaling_efficiency"] = {
+                "definition": "rate of the N-rank job / (N x the rate of one rank alone on the per-rank element count)",
+                "compute_only": res["value"] / ideal,
+                "with_allgather_of_u": (su.get("value_with_allgather") or 0.0) / ideal,
+                **{("with_allgather_of_u_%d_sample" % res[k]["samples_per_element"]):
+                   (res[k].get("value_with_allgather") or 0.0) / ideal for k in res if k.startswith("stitch_u_")},
+            }
     if second is not None:
         out[second[0]] = second[1]
     if one_rank is not None:

@@ -57,6 +57,27 @@ class ShardPlan:
 
 ALLGATHER_ALGOS = ("collective", "pairs")
 
+# xGMI on an 8-GPU MI355X node: 7 point-to-point links per GPU, ~76.8 GB/s per direction each
+XGMI_LINKS = 7
+XGMI_LINK_GBPS_PER_DIRECTION = 76.8
+
+
+def stitch_traffic_model(ne_global, world, bytes_per_element):
+    """Bytes one rank RECEIVES per stitched step (equal padded blocks, rank-major) and the xGMI time
+    floor of the two algorithms -- the model of DESIGN.md section 8, used by bench.py for the byte
+    counts it reports and for the predictions the measured N > 1 line is compared with:
+      direct all-pairs: every link carries one peer's block, all 7 at once  -> block / link rate
+      ring            : world-1 steps of one block over one link           -> (world-1) blocks / link rate
+    """
+    plan = ShardPlan(int(ne_global), int(world))
+    block = plan.max_size * int(bytes_per_element)
+    recv = (int(world) - 1) * block
+    link = XGMI_LINK_GBPS_PER_DIRECTION * 1e9
+    waves = -(-(int(world) - 1) // XGMI_LINKS) if world > 1 else 0          # more peers than links: several rounds
+    return {"block_bytes": block, "bytes_received_per_rank_per_step": recv,
+            "direct_all_pairs_floor_s": waves * block / link, "ring_floor_s": (int(world) - 1) * block / link,
+            "inbound_GBps_at_direct_floor": (recv / (waves * block / link) / 1e9) if world > 1 else 0.0}
+
 
 def allgather_flat(out, src, rank, world, *, algo="collective", group=None):
     """Every rank contributes ``src`` (1-D, equal length on all ranks) and receives all of them,

@@ -130,3 +130,87 @@ def test_bench_refuses_wrong_rank_count():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8"], env=env,
                        capture_output=True, text=True, timeout=60)
     assert r.returncode == 2 and "refusing" in r.stderr and r.stdout == ""
+
+
+def test_stitch_traffic_model_matches_design():
+    """The byte counts bench.py reports for the stitch and DESIGN.md section 8's predictions come from
+    one function: BASELINE config 3 on 8 ranks, u at 2 / 1 points per element and W."""
+    from hybrid_fem_lssvr_amd.distributed import ShardPlan, stitch_traffic_model
+    ne, world = 10000008, 8
+    assert ShardPlan(ne, world).max_size == 1250001
+    m2 = stitch_traffic_model(ne, world, 16)
+    assert m2["bytes_received_per_rank_per_step"] == 7 * 1250001 * 16 == 140000112      # "140 MB"
+    assert abs(m2["direct_all_pairs_floor_s"] - 20000016 / 76.8e9) < 1e-12              # 0.26 ms at 100 %, 0.33 ms at 80 %
+    assert abs(m2["ring_floor_s"] - 7 * 20000016 / 76.8e9) < 1e-12                      # 1.8 ms
+    assert abs(m2["inbound_GBps_at_direct_floor"] - 7 * 76.8) < 1e-6                    # 538 GB/s inbound
+    m1 = stitch_traffic_model(ne, world, 8)
+    assert m1["bytes_received_per_rank_per_step"] * 2 == m2["bytes_received_per_rank_per_step"]
+    mw = stitch_traffic_model(ne, world, 72)
+    assert mw["bytes_received_per_rank_per_step"] == 7 * 1250001 * 72                   # "630 MB"
+    # 6x the N = 1 line (1e10 el/s) = 6e10 el/s needs ne / 6e10 s per step: the 2-point stitch cannot
+    # (0.26 ms floor > 0.167 ms), the 1-point stitch can (0.13 ms) -- DESIGN.md section 8
+    assert m2["direct_all_pairs_floor_s"] > ne / 6e10 > m1["direct_all_pairs_floor_s"]
+    assert stitch_traffic_model(1000, 1, 16)["bytes_received_per_rank_per_step"] == 0
+
+
+def _bytes_worker(rank, world, port, ne, width, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from hybrid_fem_lssvr_amd.distributed import ShardPlan, allgather_flat, stitch_traffic_model
+        plan = ShardPlan(ne, world)
+        pad = plan.max_size
+        # exactly the buffers bench.py::timed_stitch gathers: equal padded blocks, rank-major
+        send = torch.full((pad * width,), float(rank + 1), dtype=torch.float64)
+        res = {}
+        for algo in ("collective", "pairs"):
+            recv = torch.zeros(world * pad * width, dtype=torch.float64)
+            allgather_flat(recv, send, rank, world, algo=algo)
+            foreign = int((recv != float(rank + 1)).sum().item()) * 8        # bytes that came from other ranks
+            res[algo] = foreign
+        q.put((rank, res, stitch_traffic_model(ne, world, 8 * width)["bytes_received_per_rank_per_step"]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,ne,width", [(2, 1001, 2), (3, 100, 1), (2, 64, 9)])
+def test_stitch_bytes_equal_the_model(world, ne, width):
+    """What a rank receives in one stitched step (every other rank's padded block) is what
+    stitch_traffic_model -- and therefore the bench line's bytes_received_per_rank_per_step -- says."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bytes_worker, args=(r, world, port, ne, width, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, res, model in got:
+        assert res["collective"] == res["pairs"] == model, (rank, res, model)
+
+
+def test_bench_self_launch_ends_siblings_on_first_failure(tmp_path):
+    """bench.py's own launcher polls its ranks: when one exits non-zero the others are terminated
+    instead of waiting in a collective for a peer that is gone."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "fake_rank.py"
+    script.write_text("import os, sys, time\n"
+                      "if os.environ['RANK'] == '1':\n    sys.exit(3)\n"
+                      "time.sleep(120)\n")
+    sys.path.insert(0, root)
+    import importlib
+    bench = importlib.import_module("bench")
+    old = bench.__file__
+    try:
+        bench.__file__ = str(script)           # self_launch starts `python <bench.__file__> args` per rank
+        t0 = time.time()
+        rc = bench.self_launch(3, [])
+    finally:
+        bench.__file__ = old
+    assert rc == 3 and time.time() - t0 < 30.0
