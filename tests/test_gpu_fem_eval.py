@@ -309,8 +309,8 @@ def test_varcoef_config5_full_size(dev, note):
     # x = -1, 0, 1 for u = sin(pi x)) the two terms are 1.5e4 times larger than their sum, so one ulp
     # in the tabulated f moves the EXACT minimiser's bubble by 1.7e-12 of itself (measured with the
     # 60-digit solve: oracle probe in DESIGN.md section 6).  kappa_e = max_k (|f~| + |b d_1|) / max_k |phi|
-    # is that amplification; the bubble is held to 1e-13 kappa_e (minimiser) / 1e-12 kappa_e (oracle),
-    # i.e. to the same 1e-13 wherever the bubble is not a difference of larger numbers.
+    # is that amplification; the bubble is held to 2e-15 kappa_e (minimiser) / 2e-14 kappa_e (oracle) --
+    # ~10x what was measured -- i.e. to the plain bar wherever the bubble is not a difference of larger numbers.
     def kappa(s0, s1):
         el = np.arange(s0, s1)
         aa, bb = nodes[el], nodes[el + 1]
@@ -328,8 +328,8 @@ def test_varcoef_config5_full_size(dev, note):
                                  coef_a=a, coef_da=da, global_domain=(-1.0, 1.0))
         assert orc.rel_l2_coef(W[s0:s0 + 5000], Wo).max() <= 1e-11
         worst = max(worst, (orc.rel_l2_bubble(W[s0:s0 + 5000], Wo) / kappa(s0, s0 + 5000)).max())
-    note("config 5 bubble / kappa vs batched oracle, 1.5e4 elements", worst, 1e-12)
-    assert worst <= 1e-12, worst
+    note("config 5 bubble / kappa vs batched oracle, 1.5e4 elements", worst, 2e-14)
+    assert worst <= 2e-14, worst                # measured 1.3e-15
     # every element: the rows enforce -a u'' - a' u' = f, i.e. u'' = -(f + a' u') / a with u' the
     # slope of the nodal values to leading order -- for the manufactured u = sin(pi x) that is
     # u'' = -pi^2 sin(pi x) whatever a is: bubble = -(u''/2)(x-a)(b-x), w_2 = -(2/3)(pi^2 h^2 / 8) sin(pi x_mid)
@@ -344,15 +344,15 @@ def test_varcoef_config5_full_size(dev, note):
         tr = cf.truth_all(nodes, values, M, 1e4, n, f, (-1.0, 1.0), sel, coef_a=a, coef_da=da)
         assert orc.rel_l2_coef(W[sel], tr).max() <= 1e-13
         bt = (orc.rel_l2_bubble(W[sel], tr) / np.array([kappa(i, i + 1)[0] for i in sel])).max()
-        note("config 5 bubble / kappa vs 60-digit minimiser", bt, 1e-13)
-        assert bt <= 1e-13, bt
+        note("config 5 bubble / kappa vs 60-digit minimiser", bt, 2e-15)
+        assert bt <= 2e-15, bt                  # measured 1.5e-16
         # ... and where the bubble is well conditioned (kappa < 10) the plain 1e-13 holds
         mid = [250000, 333333, 600000]
         trm = cf.truth_all(nodes, values, M, 1e4, n, f, (-1.0, 1.0), mid, coef_a=a, coef_da=da)
         assert max(kappa(i, i + 1)[0] for i in mid) < 10.0
         bm = orc.rel_l2_bubble(W[mid], trm).max()
-        note("config 5 bubble vs 60-digit minimiser, well-conditioned elements", bm, 1e-13)
-        assert bm <= 1e-13, bm
+        note("config 5 bubble vs 60-digit minimiser, well-conditioned elements", bm, 5e-15)
+        assert bm <= 5e-15, bm                  # measured 6.4e-16
 
 
 def test_step_is_hip_graph_capturable(dev):
