@@ -38,6 +38,14 @@ namespace lssvr {
 
 constexpr int kReseed = 64;   // in-kernel rhs: the (sin, cos) rotation is re-seeded every 64 points
 
+// MEASUREMENT AID (never defined in the shipped build; scripts/decompose_small.sh builds the variants):
+// LSSVR_DECOMP = 1 empty body (launch, wave ramp, nothing else), 2 the four loads of an element and
+// nothing else, 3 loads + all arithmetic but no store, 4 loads + the transposed store but no arithmetic.
+// The differences attribute the kernel's time at BASELINE config 2.
+#ifndef LSSVR_DECOMP
+#define LSSVR_DECOMP 0
+#endif
+
 template <int M, int RHS>
 constexpr int kChebTilePerWave =
     (RHS == LSSVR_RHS_ARRAY && 64 * 9 > 64 * M) ? 64 * 9 : 64 * M;   // output tile / rhs staging
@@ -123,6 +131,9 @@ __device__ __forceinline__ void enhance_small_body_cheb(const EnhanceArgs& p, co
   const int64_t e = (int64_t)block * kBlock + tid;
   double w[M];
   int st = LSSVR_ST_OK;
+#if LSSVR_DECOMP == 1
+  if (p.ne >= 0) return;
+#endif
 
   const bool scattered = p.elem_ids != nullptr || (p.ldw != 0 && p.ldw != M);
   // Every lane runs the body (lanes past the end of the last wave on a duplicate of the last
@@ -148,6 +159,15 @@ __device__ __forceinline__ void enhance_small_body_cheb(const EnhanceArgs& p, co
     const double gl = (eg == 0 && a == p.gxmin) ? p.bc_left : p.u[id];
     const double gr = (eg == p.ne_global - 1 && b == p.gxmax) ? p.bc_right : p.u[id + 1];
     const double inv_gamma = p.gamma_values ? rcp_newton(p.gamma_values[id]) : p.inv_gamma;
+#if LSSVR_DECOMP == 2
+    if (a + b + gl + gr == 1.2345e300 && p.status) p.status[id] = 1;      // (never: keeps the loads alive)
+    return;
+#endif
+#if LSSVR_DECOMP == 4
+#pragma unroll
+    for (int i = 0; i < M; ++i) w[i] = a + (double)i * gl + b * gr;
+    if (live && p.status) p.status[id] = st;
+#else
 
     const DomainMap dm = map_params(a, b);
     const int n = p.n;
@@ -443,6 +463,15 @@ __device__ __forceinline__ void enhance_small_body_cheb(const EnhanceArgs& p, co
       w[1] = 0.5 * (gr - gl);
       if (live && p.fail_count) atomicAdd(p.fail_count, 1);
     }
+#if LSSVR_DECOMP == 3
+    {
+      double acc = 0.0;
+#pragma unroll
+      for (int i = 0; i < M; ++i) acc += w[i];
+      if (acc == 1.2345e300 && p.status) p.status[id] = st;              // (never: keeps the arithmetic alive)
+      return;
+    }
+#endif
     if (live && p.status) p.status[id] = st;
     if (live && scattered) {
       // heterogeneous launch: rows go to the mesh index, ldw apart (direct stores)
@@ -450,6 +479,7 @@ __device__ __forceinline__ void enhance_small_body_cheb(const EnhanceArgs& p, co
 #pragma unroll
       for (int i = 0; i < M; ++i) Wrow[i] = w[i];
     }
+#endif   // LSSVR_DECOMP != 4
   }
   if (scattered) return;
 
