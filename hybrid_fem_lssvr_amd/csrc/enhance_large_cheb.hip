@@ -351,6 +351,7 @@ constexpr int kWsStride = kMomentWsStride; // per element: m_0..m_60 at [0, 61),
 constexpr int kMomBlock = 256;
 template <int RHS>
 __global__ __launch_bounds__(kMomBlock, 2) void moments_kernel(EnhanceArgs p, double* __restrict__ ws) {
+  __shared__ double mtile[(kMomBlock / 64) * 64 * 33];      // 16.5 KB per wave: the store transposition
   const int64_t e = (int64_t)blockIdx.x * kMomBlock + threadIdx.x;
   const bool live = e < p.ne;
   const int64_t ec = live ? e : p.ne - 1;
@@ -419,24 +420,46 @@ __global__ __launch_bounds__(kMomBlock, 2) void moments_kernel(EnhanceArgs p, do
       }
     }
   }
-  if (!live) return;
-  double* const o = ws + e * kWsStride;
+  // ---- the 96 numbers of the element -> workspace row, COALESCED: written lane by lane (every store
+  // instruction 64 rows apart, 768 B stride) they cost 64 cache-line transactions per instruction --
+  // 6 144 per wave, which at 1e5 elements was a third of the kernel (a two-lanes-per-element build with
+  // twice the store instructions took 50 us MORE, which is how it showed).  Three passes of 32 columns
+  // through a wave-private LDS tile (row pitch 33: conflict-free both ways) turn them into stores of
+  // two 256-byte row segments each: 4 full lines per instruction.
   const double m0 = (double)n;
-  o[0] = m0;
-#pragma unroll
-  for (int d = 1; d <= kTop; ++d) o[d] = mom[d];
-#pragma unroll
-  for (int j = 16; j <= 30; ++j) o[2 * j] = fma(2.0, sq[j - 16], -m0);
-#pragma unroll
-  for (int j = 15; j <= 29; ++j) o[2 * j + 1] = fma(2.0, nb[j - 15], -mom[1]);
-  // the element's end points and boundary values travel with the moments (Dual.py:65-75 rule)
   const int64_t eg = id + p.elem_offset;
-  o[61] = a;
-  o[62] = b;
-  o[63] = (eg == 0 && a == p.gxmin) ? p.bc_left : p.u[id];
+  const double gl = (eg == 0 && a == p.gxmin) ? p.bc_left : p.u[id];          // Dual.py:65-75 rule
+  const double gr = (eg == p.ne_global - 1 && b == p.gxmax) ? p.bc_right : p.u[id + 1];
+  auto column = [&](auto ic) -> double {                 // workspace column `c` of this lane's element
+    constexpr int c = decltype(ic)::value;
+    if constexpr (c == 0) return m0;
+    else if constexpr (c <= kTop) return mom[c];
+    else if constexpr (c <= 60) {
+      if constexpr (c & 1) return fma(2.0, nb[(c - 1) / 2 - 15], -mom[1]);   // m_{2j+1} = 2 sum T_j T_{j+1} - m_1
+      else return fma(2.0, sq[c / 2 - 16], -m0);                            // m_{2j}   = 2 sum T_j^2 - m_0
+    } else if constexpr (c == 61) return a;
+    else if constexpr (c == 62) return b;
+    else if constexpr (c == 63) return gl;
+    else if constexpr (c < 95) return rr[c - 64];
+    else return gr;
+  };
+  const int lane = threadIdx.x & 63;
+  double* const tl = mtile + (threadIdx.x >> 6) * (64 * 33);
+  const int64_t e0 = (int64_t)blockIdx.x * kMomBlock + (threadIdx.x & ~63);      // the wave's first element
+  static_for<0, 3>([&](auto pc) {
+    constexpr int c0 = decltype(pc)::value * 32;
+    wave_lds_sync();                                   // the previous pass's reads are done
+    static_for<0, 32>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      tl[lane * 33 + j] = column(std::integral_constant<int, c0 + j>{});
+    });
+    wave_lds_sync();
 #pragma unroll
-  for (int i = 0; i <= kTop; ++i) o[64 + i] = rr[i];
-  o[95] = (eg == p.ne_global - 1 && b == p.gxmax) ? p.bc_right : p.u[id + 1];
+    for (int i = 0; i < 32; ++i) {
+      const int row = 2 * i + (lane >> 5), cc = lane & 31;
+      if (e0 + row < p.ne) ws[(e0 + row) * kWsStride + c0 + cc] = tl[row * 33 + cc];
+    }
+  });
 }
 
 // Phase 2 alone: a workgroup of four waves = sixteen elements (four per wave); the moments come
