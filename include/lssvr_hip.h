@@ -64,9 +64,13 @@ extern "C" {
 #define LSSVR_SOLVER_DUAL   1 /* north_star's dual Gram form (K + I/gamma) alpha = y: kernel
                                  Gram matrix of the collocation rows (boundary rows eliminated
                                  as a 2x2 block pivot), Jacobi-equilibrated, LU with partial
-                                 pivoting, two steps of iterative refinement.  n_colloc <= 64,
-                                 M <= 33, Poisson and variable-coefficient rows.  <= 1e-12 of
-                                 the exact minimiser on every BASELINE config  */
+                                 pivoting, up to 3 safeguarded steps of iterative refinement
+                                 (operator-form residual in compensated arithmetic).  n_colloc <= 64,
+                                 M <= 33, Poisson and variable-coefficient rows.  Measured against the
+                                 exact minimiser: <= 1e-12 on BASELINE configs 1-3, <= 5e-11 at degree
+                                 32 / 64 points (config 4), 1e-8 where n_colloc ~ M .. M+6 (DESIGN.md
+                                 section 3.2b).  FP64 vector FMAs only, no MFMA; 40x slower than
+                                 LSSVR_SOLVER_PRIMAL: the cross-check solver                      */
 #define LSSVR_SOLVER_PRIMAL_MOMENT 3 /* same algorithm as PRIMAL as the kernel sequence of
                                  csrc/enhance_large_cheb.hip (Chebyshev-moment Gram, four systems
                                  per wave in the LDL^T) for ANY M, Poisson rows -- what PRIMAL

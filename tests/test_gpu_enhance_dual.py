@@ -69,13 +69,14 @@ def test_dual_golden(dev, golden, name, tol_truth, tol_ref):
 @pytest.mark.parametrize("M,n,tol", [(12, 6, 1e-13), (12, 10, 1e-13), (20, 8, 1e-13), (24, 16, 1e-13),
                                      (32, 20, 1e-13), (33, 12, 1e-13), (9, 3, 1e-13), (6, 2, 1e-13),
                                      (17, 12, 1e-13), (22, 12, 1e-13),
-                                     (32, 29, 1e-10), (33, 31, 1e-10), (33, 33, 1e-6), (33, 38, 1e-6)])
+                                     (32, 29, 1e-10), (33, 31, 1e-10), (33, 33, 1e-7), (33, 38, 5e-8)])
 def test_dual_where_primal_degrades(dev, M, n, tol):
     """n < M - 2: the primal normal equations are rank deficient (O(1) errors in float64) and
     lssvr_enhance routes here; the dual solve reaches the 60-digit minimiser.  n ~ M - 2 .. M + 6
     equispaced points (last four rows): an ill-conditioned Vandermonde in any formulation -- measured
     dual / primal: 7e-12 / - (32, 29), 3e-12 / 3e-6 (33, 31), 2e-8 / 5e-10 (33, 33), 1e-8 / 2e-13
-    (33, 38); no BASELINE configuration is there."""
+    (33, 38); the bars of the last two sit at 5x those measurements (a regression by that factor
+    shows).  No BASELINE configuration is there."""
     ne = 37
     nodes = np.linspace(-1, 1, ne + 1)
     values = orc.fem_p1_solve(nodes)
