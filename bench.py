@@ -71,6 +71,24 @@ def algorithmic_flops_dual(M, n):
     return (n + 2) * (n + 3) * M + (1.0 / 3.0) * (n + 2) ** 3 + 2 * (n + 2) ** 2 + 2 * M * (n + 2)
 
 
+def executed_fraction(key, ne, kernel_s):
+    """Issue-slot utilisation of the FP64 pipe by what the kernel actually EXECUTES (the nominal
+    `frac` prices SURVEY's direct-Gram flop count, which the Chebyshev-moment kernels do not execute): VALU
+    wave-instructions per launch (profiles/instruction_counts.json: rocprofv3 SQ_INSTS_VALU of this kernel) x 4
+    cycles each / (SIMDs x 2.4 GHz x measured duration).  <= 1 by construction; None when the kernel has no count."""
+    try:
+        tab = json.load(open(os.path.join(ROOT, "profiles", "instruction_counts.json")))
+        ent = tab[key]
+    except Exception:
+        return None
+    per_el = ent["valu_per_element"] if "valu_per_element" in ent else ent["valu_per_wave"] / 64.0
+    cycles = per_el * ne * 4.0 + ent.get("mfma_4x4x4_per_element", 0.0) * ne * 16.0     # (a 4x4x4 MFMA: ~20 cycles)
+    return {"issue_slot_frac": cycles / (1024 * 2.4e9 * kernel_s), "valu_instructions_per_element": per_el,
+            "source": ent["source"],
+            "meaning": "fraction of the chip's FP64 issue slots (1024 SIMDs x 2.4 GHz / 4 cycles per wave-instruction) "
+                       "the kernel's executed vector instructions fill during the measured launch"}
+
+
 def algorithmic_bytes(M):
     """node coordinate 8 B + nodal value 8 B + 8 M B of coefficients."""
     return 16 + 8 * M
@@ -732,10 +750,10 @@ def run_config5(args, D, M, n, ne, lo, hi, dev, cpu_res):
                                    out=w["W"], status=w["st"], point_major=w["pm"], **kw)
 
     def step_fn(w):
-        def go(stream):
-            ops.p1_assemble(w["x"], 2, rhs_quad=w["fq"], a_quad=w["aq"], out=w["bands"], stream=stream)
-            enh(w, stream=stream)
-        return go
+        plan = ops.StepPlanVarcoef(w["x"], w["u"], M, GAMMA, n, w["a"], w["da"], w["f"], w["fq"], w["aq"],
+                                   nquad=2, point_major=w["pm"], global_domain=w["gd"], bands=w["bands"],
+                                   out=w["W"], status=w["st"])
+        return plan.launch
 
     def timed(w, steps, warmup):
         go = step_fn(w)
@@ -852,7 +870,7 @@ def run_config5(args, D, M, n, ne, lo, hi, dev, cpu_res):
                          "seed 20260130), manufactured u = sin(pi x); %d P1 elements on [%g, %g] (h = %.6g), Legendre "
                          "degree %d (M = %d), %d collocation points, gamma = 1e4; a, a', f tabulated per element and "
                          "point (3 x %d doubles per element, resident in HBM, %s); step = element-local P1 assembly "
-                         "(a-weighted stiffness, 2-point Gauss) + per-element Gram + solve: two launches"
+                         "(a-weighted stiffness, 2-point Gauss) + per-element Gram + solve: one fused launch (lssvr_step_varcoef)"
                          % (ne, lo, hi, (hi - lo) / ne, args.degree, M, n, n,
                             "point-major t[k, e]" if pm else "element-major t[e, k]")),
             "elements_per_gpu": ne,
@@ -880,6 +898,8 @@ def run_config5(args, D, M, n, ne, lo, hi, dev, cpu_res):
         },
         "roofline_fp64": {
             "bound": "fp64-valu",
+            "executed": executed_fraction("c5_point_major_M%d_n%d" % (M, n) if pm else "c5_element_major_M%d_n%d" % (M, n),
+                                          ne, k_avg),
             "achieved": tfl,
             "peak": FP64_PEAK_TFLOPS,
             "unit": "TFLOP/s",
@@ -1151,6 +1171,11 @@ def run_single(args, D, M, n, ne_glob, lo, hi, dev, cpu_res, use_dist):
             "flops_per_element": flops,
             "flops_formula": "SURVEY.md 8(d) " + ("dual" if dual else "primal") + " form (direct Gram); the kernel's "
                              "Chebyshev-moment Gram executes fewer (DESIGN.md section 2b)",
+            "achieved_is": "direct-Gram-EQUIVALENT TFLOP/s (algorithmic flops of SURVEY.md 8(d) / measured duration), "
+                           "not executed flops: see `executed`",
+            "executed": executed_fraction(("dual_M%d_n%d" % (M, n)) if dual else
+                                          ("small_M%d_n%d_sin" % (M, n)) if M <= 22 else
+                                          ("large_pair_M%d_n%d" % (M, n)), ne_loc, k_dur),
             "elements_per_launch": ne_loc,
             "kernel_us_avg": k_dur * 1e6,
             "kernel_us_median": k_med * 1e6,

@@ -275,6 +275,54 @@ int lssvr_enhance_varcoef(const double* x, const double* u, int64_t ne, int64_t 
                                   W, status, fail_count, nullptr, 0, stream, nullptr);
 }
 
+int lssvr_step_varcoef(const double* x, const double* u, int64_t ne, int64_t elem_offset,
+                       int64_t ne_global, double gxmin, double gxmax, double bc_left, double bc_right,
+                       int M, int n_colloc, double gamma, const double* a_values,
+                       const double* da_values, const double* rhs_values, int table_layout, int nquad,
+                       const double* rhs_quad, const double* a_quad, double* diag, double* off,
+                       double* load, double* W, int32_t* status, int32_t* fail_count, void* stream) {
+  lssvr::EnhanceArgs a;
+  int rc = fill_enhance_args(a, x, u, ne, elem_offset, ne_global, gxmin, gxmax, bc_left, bc_right,
+                             M, n_colloc, gamma, W);
+  if (rc != LSSVR_OK) return rc;
+  if (ne < 1) return fail(LSSVR_ERR_SIZE, "ne = %lld < 1", (long long)ne);
+  if (!a_values || !da_values || !rhs_values)
+    return fail(LSSVR_ERR_NULL, "a_values, da_values and rhs_values must be non-NULL");
+  if (!rhs_quad || !a_quad) return fail(LSSVR_ERR_NULL, "rhs_quad and a_quad must be non-NULL");
+  if (!diag || !off || !load) return fail(LSSVR_ERR_NULL, "diag, off, load must be non-NULL");
+  if (nquad < 1 || nquad > 5) return fail(LSSVR_ERR_QUAD, "nquad = %d outside [1,5]", nquad);
+  if (table_layout != LSSVR_TABLE_ELEMENT_MAJOR && table_layout != LSSVR_TABLE_POINT_MAJOR)
+    return fail(LSSVR_ERR_SIZE, "unknown table_layout %d", table_layout);
+  if (n_colloc < M - 2)
+    return fail(LSSVR_ERR_SOLVER, "lssvr_step_varcoef: n_colloc = %d < M-2 = %d: use lssvr_p1_assemble + "
+                                  "lssvr_enhance_varcoef (dual solver)", n_colloc, M - 2);
+  a.rhs_id = LSSVR_RHS_ARRAY;
+  a.rhs_values = rhs_values;
+  a.a_values = a_values;
+  a.da_values = da_values;
+  if (table_layout == LSSVR_TABLE_POINT_MAJOR) {
+    a.tab_es = 1;
+    a.tab_ps = ne;
+  }
+  a.status = status;
+  a.fail_count = fail_count;
+  lssvr::P1Args p{};
+  p.x = x;
+  p.ne = ne;
+  p.nquad = nquad;
+  p.rhs_id = LSSVR_RHS_ARRAY;
+  p.rhs_quad = rhs_quad;
+  p.a_quad = a_quad;
+  p.diag = diag;
+  p.off = off;
+  p.load = load;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (M <= lssvr::kStepVarcoefFusedMaxM) return check_launch(lssvr::step_small_vc(a, p, s), "step_small_vc");
+  rc = check_launch(lssvr::p1_assemble(p, s), "p1_assemble");
+  if (rc != LSSVR_OK) return rc;
+  return enhance_dispatch(a, LSSVR_SOLVER_PRIMAL, s, nullptr);
+}
+
 int64_t lssvr_enhance_varcoef_work_bytes(int64_t ne, int M, int n_colloc) {
   (void)ne; (void)M; (void)n_colloc;
   return 0;

@@ -8,7 +8,9 @@ namespace lssvr {
 #define LSSVR_DECLARE_SMALL_RANGE(NAME)                                                          \
   hipError_t enhance_small_##NAME(const EnhanceArgs& a, hipStream_t s, const LaunchOpts* o);     \
   hipError_t step_small_##NAME(const EnhanceArgs& e, const P1Args& a, const QuadRule& q,         \
-                               hipStream_t s, const LaunchOpts* o);
+                               hipStream_t s, const LaunchOpts* o);                              \
+  hipError_t step_small_vc_##NAME(const EnhanceArgs& e, const P1Args& a, const QuadRule& q,      \
+                                  hipStream_t s, const LaunchOpts* o);
 LSSVR_DECLARE_SMALL_RANGE(a)   // M = 2..10
 LSSVR_DECLARE_SMALL_RANGE(b)   // M = 11..15
 LSSVR_DECLARE_SMALL_RANGE(c)   // M = 16..19
@@ -28,6 +30,15 @@ hipError_t step_small(const EnhanceArgs& e, const P1Args& a, hipStream_t s, cons
   if (e.M <= 15) return step_small_b(e, a, q, s, o);
   if (e.M <= 19) return step_small_c(e, a, q, s, o);
   return step_small_d(e, a, q, s, o);
+}
+
+// variable-coefficient step in one launch (M <= 12; hipErrorInvalidValue above: the caller issues two)
+hipError_t step_small_vc(const EnhanceArgs& e, const P1Args& a, hipStream_t s, const LaunchOpts* o) {
+  QuadRule q;
+  if (!quad_rule(a.nquad, q)) return hipErrorInvalidValue;
+  if (e.M <= 10) return step_small_vc_a(e, a, q, s, o);
+  if (e.M <= 15) return step_small_vc_b(e, a, q, s, o);
+  return hipErrorInvalidValue;
 }
 
 }  // namespace lssvr

@@ -398,6 +398,22 @@ __global__ __launch_bounds__(kBlock) void step_small_kernel(EnhanceArgs p, P1Arg
   }
 }
 
+// The same fusion for BASELINE config 5: variable-coefficient enhancement (tabulated a, a', f) +
+// the a-weighted P1 assembly from tabulated quadrature values, ONE grid.  Instantiated up to
+// kStepVcMaxM (the direct-Gram bodies grow as M^2: above, lssvr_step_varcoef issues two launches).
+constexpr int kStepVcMaxM = 12;
+template <int M, int RHS>
+__global__ __launch_bounds__(kBlock) void step_small_vc_kernel(EnhanceArgs p, P1Args a, QuadRule q,
+                                                                unsigned eblocks) {
+  __shared__ double tile[(kBlock / 64) * kSmallTilePerWave<M, RHS, true>];
+  if (blockIdx.x < eblocks) {
+    enhance_small_body<M, RHS, true>(p, blockIdx.x, tile);
+  } else {
+    const int64_t i = (int64_t)(blockIdx.x - eblocks) * kBlock + threadIdx.x;
+    if (i <= a.ne) p1_node<false>(a, q, i);
+  }
+}
+
 // ----------------------------------------------------------------------------
 // dispatch
 // ----------------------------------------------------------------------------
@@ -418,6 +434,20 @@ static hipError_t launch_step(const EnhanceArgs& e, const P1Args& a, const QuadR
   return launch(step_small_kernel<M>, dim3(eb + ab), dim3(kBlock), s, o, e, a, q, eb);
 }
 
+template <int M>
+static hipError_t launch_step_vc(const EnhanceArgs& e, const P1Args& a, const QuadRule& q,
+                                 hipStream_t s, const LaunchOpts* o) {
+  if constexpr (M <= kStepVcMaxM) {
+    const unsigned eb = (unsigned)((e.ne + kBlock - 1) / kBlock);
+    const unsigned ab = (unsigned)((a.ne + 1 + kBlock - 1) / kBlock);
+    if (e.tab_ps != 1)
+      return launch(step_small_vc_kernel<M, LSSVR_RHS_ARRAY_PM>, dim3(eb + ab), dim3(kBlock), s, o, e, a, q, eb);
+    return launch(step_small_vc_kernel<M, LSSVR_RHS_ARRAY>, dim3(eb + ab), dim3(kBlock), s, o, e, a, q, eb);
+  } else {
+    return hipErrorInvalidValue;
+  }
+}
+
 // Each translation unit enhance_small_*.hip instantiates a range of M (the fully unrolled
 // kernels are large: one TU per range keeps the build parallel) through this macro.
 #define LSSVR_DEFINE_SMALL_RANGE(NAME, FOR_EACH_M)                                              \
@@ -435,6 +465,14 @@ static hipError_t launch_step(const EnhanceArgs& e, const P1Args& a, const QuadR
       default:                                                                                   \
         return hipErrorInvalidValue;                                                             \
     }                                                                                            \
+  }                                                                                              \
+  hipError_t step_small_vc_##NAME(const EnhanceArgs& e, const P1Args& a, const QuadRule& q,      \
+                                  hipStream_t s, const LaunchOpts* o) {                          \
+    switch (e.M) {                                                                               \
+      FOR_EACH_M(LSSVR_SMALL_CASE_STEP_VC)                                                       \
+      default:                                                                                   \
+        return hipErrorInvalidValue;                                                             \
+    }                                                                                            \
   }
 
 #define LSSVR_SMALL_CASE_ENH(MM)                                                     \
@@ -447,5 +485,8 @@ static hipError_t launch_step(const EnhanceArgs& e, const P1Args& a, const QuadR
 #define LSSVR_SMALL_CASE_STEP(MM) \
   case MM:                        \
     return launch_step<MM>(e, a, q, s, o);
+#define LSSVR_SMALL_CASE_STEP_VC(MM) \
+  case MM:                           \
+    return launch_step_vc<MM>(e, a, q, s, o);
 
 }  // namespace lssvr

@@ -132,6 +132,8 @@ hipError_t p1_assemble(const P1Args& a, hipStream_t s);
 // assembly + enhancement of the same mesh in ONE launch (lane-per-element path, in-kernel rhs)
 hipError_t step_small(const EnhanceArgs& e, const P1Args& a, hipStream_t s,
                       const LaunchOpts* o = nullptr);
+constexpr int kStepVarcoefFusedMaxM = 12;   // lssvr_step_varcoef: one launch up to here, two above
+hipError_t step_small_vc(const EnhanceArgs& e, const P1Args& a, hipStream_t s, const LaunchOpts* o = nullptr);
 hipError_t quad_points(const double* x, int64_t ne, int nquad, double* xq, hipStream_t s);
 
 int64_t tridiag_work_bytes(int64_t ne);

@@ -429,6 +429,55 @@ def enhance_varcoef(x, u, M, gamma, n_colloc, a_values, da_values, rhs_values, *
     return out, status
 
 
+class StepPlanVarcoef:
+    """One step of BASELINE config 5 (a-weighted P1 assembly from tabulated quadrature values +
+    variable-coefficient enhancement from tabulated a, a', f) bound once, launched many times:
+    ``lssvr_step_varcoef`` -- one launch for M <= 12."""
+
+    def __init__(self, x, u, M, gamma, n_colloc, a_values, da_values, rhs_values, rhs_quad, a_quad, *,
+                 nquad=2, point_major=False, elem_offset=0, ne_global=None, global_domain, bc=(0.0, 0.0),
+                 bands=None, out=None, status=None, fail_count=None):
+        self.lib = _capi.load()
+        _dev(x, "x")
+        _dev(u, "u")
+        ne = x.numel() - 1
+        dev = x.device
+        if x.numel() != u.numel() or x.dim() != 1:
+            raise ValueError("x and u must be 1-D with equal length ne+1")
+        for t, nm, cnt in ((a_values, "a_values", ne * n_colloc), (da_values, "da_values", ne * n_colloc),
+                           (rhs_values, "rhs_values", ne * n_colloc), (rhs_quad, "rhs_quad", ne * nquad),
+                           (a_quad, "a_quad", ne * nquad)):
+            _dev(t, nm)
+            if t.numel() != cnt:
+                raise ValueError(f"{nm} must hold {cnt} doubles")
+        if ne_global is None:
+            ne_global = elem_offset + ne
+        self.bands = bands or {
+            "diag": torch.empty(ne + 1, dtype=torch.float64, device=dev),
+            "off": torch.empty(ne, dtype=torch.float64, device=dev),
+            "load": torch.empty(ne + 1, dtype=torch.float64, device=dev),
+        }
+        for k, cnt in (("diag", ne + 1), ("off", ne), ("load", ne + 1)):
+            _dev(self.bands[k], k)
+            if self.bands[k].numel() != cnt:
+                raise ValueError(f"bands[{k!r}] must hold {cnt} doubles")
+        self.W, self.status = _check_buffers(ne, M, n_colloc, x, out=out, status=status, fail_count=fail_count)
+        self._keep = (x, u, a_values, da_values, rhs_values, rhs_quad, a_quad, fail_count)
+        self._args = (_ptr(x), _ptr(u), ne, int(elem_offset), int(ne_global),
+                      float(global_domain[0]), float(global_domain[1]), float(bc[0]), float(bc[1]),
+                      int(M), int(n_colloc), float(gamma), _ptr(a_values), _ptr(da_values), _ptr(rhs_values),
+                      TABLE_POINT_MAJOR if point_major else TABLE_ELEMENT_MAJOR, int(nquad),
+                      _ptr(rhs_quad), _ptr(a_quad),
+                      _ptr(self.bands["diag"]), _ptr(self.bands["off"]), _ptr(self.bands["load"]),
+                      _ptr(self.W), _ptr(self.status), _ptr(fail_count))
+
+    def launch(self, stream=None):
+        rc = self.lib.lssvr_step_varcoef(*self._args, _stream(stream))
+        if rc < 0:
+            _capi.check(rc, "lssvr_step_varcoef")
+        return self.W, self.status
+
+
 def colloc_points(x, n_colloc, *, stream=None, point_major=False):
     """``np.linspace(x[e], x[e+1], n)`` for every element (Dual.py:40) -> float64[ne, n], or
     float64[n, ne] with ``point_major`` (the same values transposed: tabulate ``rhs_func`` / a / a'

@@ -221,6 +221,22 @@ int lssvr_enhance_varcoef_ws(const double* x, const double* u, int64_t ne,
                              void* work, int64_t work_bytes, void* stream, float* kernel_ms_host);
 
 /*
+ * lssvr_step_varcoef -- one whole step of BASELINE config 5 on one mesh shard: the a-weighted P1
+ * assembly (lssvr_p1_assemble with LSSVR_RHS_ARRAY tables rhs_quad / a_quad at the nquad Gauss points,
+ * lssvr_quad_points) + lssvr_enhance_varcoef (a_values / da_values / rhs_values at the collocation
+ * points, table_layout = LSSVR_TABLE_*), as disjoint block ranges of ONE grid for M <= 12 (two
+ * launches above).  Primal solver only (n_colloc >= M-2).  Arguments as in the two calls.  ABI 4.
+ */
+int lssvr_step_varcoef(const double* x, const double* u, int64_t ne,
+                       int64_t elem_offset, int64_t ne_global,
+                       double gxmin, double gxmax, double bc_left, double bc_right,
+                       int M, int n_colloc, double gamma,
+                       const double* a_values, const double* da_values, const double* rhs_values,
+                       int table_layout, int nquad, const double* rhs_quad, const double* a_quad,
+                       double* diag, double* off, double* load,
+                       double* W, int32_t* status, int32_t* fail_count, void* stream);
+
+/*
  * lssvr_enhance_subset -- heterogeneous meshes (per-element gamma, degree and
  * collocation count; the reference has one lssvr_M / lssvr_gamma for the whole mesh,
  * Dual.py:101).  Enhances the nsub elements elem_ids[0..nsub) of a shard of ne_mesh elements

@@ -101,3 +101,32 @@ def test_point_major_subset_and_shared(dev):
                                global_domain=(-1.0, 1.0))
     torch.cuda.synchronize()
     assert torch.equal(S1, S2)
+
+
+@pytest.mark.parametrize("M,n,pm", [(9, 16, True), (9, 16, False), (5, 9, True), (12, 20, False), (14, 24, True)])
+def test_fused_varcoef_step_equals_separate_launches(dev, M, n, pm):
+    """lssvr_step_varcoef (a-weighted P1 assembly + variable-coefficient enhancement: one grid for
+    M <= 12, two launches above) == lssvr_p1_assemble + lssvr_enhance_varcoef, bit for bit, both layouts."""
+    import torch
+    from hybrid_fem_lssvr_amd import ops
+    a, da, f = orc.varcoef_functions(*orc.varcoef_params())
+    ne = 1237
+    nodes = np.linspace(-1, 1, ne + 1)
+    values = orc.fem_p1_solve(nodes, rhs=f, coef_a=a)
+    x, u = _t(nodes, dev), _t(values, dev)
+    xc = ops.colloc_points(x, n, point_major=pm).cpu().numpy()
+    xq = ops.quad_points(x, 2).cpu().numpy()
+    tabs = [_t(t(xc), dev) for t in (a, da, f)]
+    fq, aq = _t(f(xq), dev), _t(a(xq), dev)
+    plan = ops.StepPlanVarcoef(x, u, M, 1e4, n, *tabs, fq, aq, point_major=pm, global_domain=(-1.0, 1.0))
+    W, st = plan.launch()
+    torch.cuda.synchronize()
+    W2, st2 = ops.enhance_varcoef(x, u, M, 1e4, n, *tabs, global_domain=(-1.0, 1.0), point_major=pm)
+    b2 = ops.p1_assemble(x, 2, rhs_quad=fq, a_quad=aq)
+    torch.cuda.synchronize()
+    assert int(st.sum()) == 0 and torch.equal(W, W2) and torch.equal(st, st2)
+    for k in ("diag", "off", "load"):
+        assert torch.equal(plan.bands[k], b2[k]), k
+    # the assembled system solves to the nodal values the oracle's P1 step gives
+    uu = ops.tridiag_dirichlet_solve(plan.bands["diag"], plan.bands["off"], plan.bands["load"]).cpu().numpy()
+    assert np.max(np.abs(uu - values)) < 1e-9
