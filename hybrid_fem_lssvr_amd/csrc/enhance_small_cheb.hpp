@@ -40,7 +40,8 @@ constexpr int kReseed = 64;   // in-kernel rhs: the (sin, cos) rotation is re-se
 
 // MEASUREMENT AID (never defined in the shipped build; scripts/decompose_small.sh builds the variants):
 // LSSVR_DECOMP = 1 empty body (launch, wave ramp, nothing else), 2 the four loads of an element and
-// nothing else, 3 loads + all arithmetic but no store, 4 loads + the transposed store but no arithmetic.
+// nothing else, 3 loads + all arithmetic but no store, 4 loads + the transposed store but no arithmetic,
+// 5 the full kernel with per-lane row stores instead of the transposed coalesced ones.
 // The differences attribute the kernel's time at BASELINE config 2.
 #ifndef LSSVR_DECOMP
 #define LSSVR_DECOMP 0
@@ -135,7 +136,11 @@ __device__ __forceinline__ void enhance_small_body_cheb(const EnhanceArgs& p, co
   if (p.ne >= 0) return;
 #endif
 
+#if LSSVR_DECOMP == 5
+  const bool scattered = true;                 // (measurement: per-lane row stores instead of the LDS transposition)
+#else
   const bool scattered = p.elem_ids != nullptr || (p.ldw != 0 && p.ldw != M);
+#endif
   // Every lane runs the body (lanes past the end of the last wave on a duplicate of the last
   // element, their stores masked): tabulated inputs are loaded cooperatively by the wave.
   bool live = e < p.ne;

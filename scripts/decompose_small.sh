@@ -10,7 +10,7 @@ mkdir -p ../../build/decomp
 FL="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math"
 OBJS=$(ls *.o | grep -v '^enhance_small_a.o$')
 cp liblssvr_hip.so ../../build/decomp/lib_full.so
-for v in empty:1 loads:2 nostore:3 noarith:4; do
+for v in empty:1 loads:2 nostore:3 noarith:4 directstore:5; do
   n=${v%%:*}; d=${v#*:}
   /opt/rocm/bin/hipcc $FL -DLSSVR_DECOMP=$d -c enhance_small_a.hip -o /tmp/esa_decomp_$n.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build/decomp/lib_$n.so $OBJS /tmp/esa_decomp_$n.o
