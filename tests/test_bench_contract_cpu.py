@@ -15,8 +15,9 @@ def _line(name):
     return json.loads(open(path).read().strip().splitlines()[-1])
 
 
-def test_default_bench_line_contract():
-    j = _line("r02_bench_n1.json")
+@pytest.mark.parametrize("name", ["r02_bench_n1.json", "r03_bench_n1.json"])
+def test_default_bench_line_contract(name):
+    j = _line(name)
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     assert j["metric"].split(",")[0] == base["metric"].split(",")[0]          # BASELINE's metric
     assert j["unit"] == "elements/s" and j["higher_is_better"] is True and j["n_gpus"] == 1
@@ -40,14 +41,26 @@ def test_default_bench_line_contract():
         assert key in c, key
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
     assert j["value"] >= 1.0e6                                              # north_star's target
+    if name.startswith("r03"):
+        # round 3: the nominal figure is labelled, the EXECUTED issue-slot fraction stands beside it
+        assert "direct-Gram-EQUIVALENT" in r["achieved_is"]
+        ex = r["executed"]
+        assert 0.0 < ex["issue_slot_frac"] <= 1.0 and ex["issue_slot_frac"] <= r["frac"]
+        assert r["bound"] == "fp64-valu"
 
 
-@pytest.mark.parametrize("name", ["r02_bench_deg32.json", "r02_bench_1e7.json", "r02_bench_dual_deg8.json"])
+@pytest.mark.parametrize("name", ["r02_bench_deg32.json", "r02_bench_1e7.json", "r02_bench_dual_deg8.json",
+                                  "r03_bench_deg32.json", "r03_bench_1e7.json", "r03_bench_dual_deg8.json",
+                                  "r03_bench_dual_deg32.json"])
 def test_other_bench_lines_are_consistent(name):
     j = _line(name)
     r = j["roofline"]
     assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-12 and 0.0 < r["frac"] < 1.5
     assert j["n_gpus"] == 1 and j["steps"] >= 1 and j["unit"] == "elements/s"
+    if name.startswith("r03"):
+        assert 0.0 < r["executed"]["issue_slot_frac"] <= 1.0        # what the kernel executes can never exceed the pipe
+        if "dual" in name:
+            assert r["bound"] == "fp64-valu" and "MFMA" not in r["pipe"].replace("no MFMA", "")
 
 
 def test_config5_bench_line_contract():
@@ -67,6 +80,7 @@ def test_config5_bench_line_contract():
     assert r["kernel_us_avg"] * 1e-3 <= 1.05 * j["ms_per_step"]
     f = j["roofline_fp64"]
     assert abs(f["frac"] - f["achieved"] / f["peak"]) <= 1e-12 and 0.0 < f["frac"] <= 1.0
+    assert 0.0 < f["executed"]["issue_slot_frac"] <= 1.0
     assert j["accuracy"]["rel_l2_vs_60_digit_minimiser"] <= 1e-13
     assert j["accuracy"]["rel_l2_bubble_vs_60_digit_minimiser"] <= 1e-13
     c = j["cpu_baseline"]
