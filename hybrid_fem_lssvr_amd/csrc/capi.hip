@@ -53,6 +53,7 @@ int fill_enhance_args(lssvr::EnhanceArgs& a, const double* x, const double* u, i
   a.inv_gamma = 1.0 / gamma;
   a.M = M;
   a.n = n_colloc;
+  a.refine = lssvr::enhance_small_refine_steps(M, n_colloc);     // (read by the Poisson lane kernel only)
   a.tab_es = n_colloc;      // tabulated arrays: element-major unless set_rhs / the caller says otherwise
   a.tab_ps = 1;
   a.W = W;
@@ -257,7 +258,13 @@ int lssvr_step(const double* x, const double* u, int64_t ne, int64_t elem_offset
   p.off = off;
   p.load = load;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (M <= lssvr::kSmallMaxM) return check_launch(lssvr::step_small(a, p, s), "step_small");
+  // (near-square regime, a.refine > 0: the refinement lives in a kernel of its own -- two launches)
+  if (M <= lssvr::kSmallMaxM && a.refine == 0) return check_launch(lssvr::step_small(a, p, s), "step_small");
+  if (M <= lssvr::kSmallMaxM) {
+    rc = check_launch(lssvr::p1_assemble(p, s), "p1_assemble");
+    if (rc != LSSVR_OK) return rc;
+    return check_launch(lssvr::enhance_small(a, s), "enhance_small(refine)");
+  }
   // large degree: the enhancement is long enough that a fused launch buys nothing
   rc = check_launch(lssvr::p1_assemble(p, s), "p1_assemble");
   if (rc != LSSVR_OK) return rc;

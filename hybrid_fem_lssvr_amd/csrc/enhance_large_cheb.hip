@@ -616,6 +616,15 @@ int enhance_refine_steps(int M, int n) {
   return excess <= 1 ? 3 : excess <= 4 ? 2 : excess <= 14 ? 1 : 0;
 }
 
+// The lane kernel (M <= 22): its normal equations are at 2e-17 from n = M - 2 on up to M = 16 and reach
+// 3e-14 (h = 1/12) .. 2e-12 (h = 0.5) at M = 22, n = 20..22: one step of the corrected semi-normal equations
+// up to an excess of 6 points, two at an excess <= 1 (measured envelope in DESIGN.md section 2).
+int enhance_small_refine_steps(int M, int n) {
+  const int excess = n - (M - 2);
+  if (M < 14 || M > kSmallMaxM || excess < 0) return 0;
+  return excess <= 1 ? 2 : excess <= 6 ? 1 : 0;
+}
+
 int64_t enhance_moment_ws_bytes(int64_t ne, int M, int n) {
   return ne * (kWsStride + (enhance_refine_steps(M, n) > 0 ? kZStride : 0)) * (int64_t)sizeof(double);
 }

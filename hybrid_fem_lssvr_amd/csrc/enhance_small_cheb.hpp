@@ -37,6 +37,7 @@
 namespace lssvr {
 
 constexpr int kReseed = 64;   // in-kernel rhs: the (sin, cos) rotation is re-seeded every 64 points
+constexpr int kRefineMinM = 14; // near-square refinement of the lane kernel: instantiated from here up
 
 // MEASUREMENT AID (never defined in the shipped build; scripts/decompose_small.sh builds the variants):
 // LSSVR_DECOMP = 1 empty body (launch, wave ramp, nothing else), 2 the four loads of an element and
@@ -120,7 +121,10 @@ __device__ __attribute__((noinline)) void cheb_slow_build(double* __restrict__ b
   }
 }
 
-template <int M, int RHS>
+// REFINE: the build with the near-square refinement loop (its own kernel, enhance_small_refine_kernel:
+// compiled into the main kernel the loop cost the NORMAL regime 15-65 % at M = 16..22 through register
+// allocation alone -- 61 -> 101 us at M = 20, n = 40 -- so launches with p.refine == 0 never see it).
+template <int M, int RHS, bool REFINE = false>
 __device__ __forceinline__ void enhance_small_body_cheb(const EnhanceArgs& p, const unsigned block,
                                                         double* __restrict__ tile) {
   constexpr int MR = M - 2;
@@ -406,22 +410,24 @@ __device__ __forceinline__ void enhance_small_body_cheb(const EnhanceArgs& p, co
           G[tri(c, j)] = lcj;
         }
       }
-      // forward  L y = rhs
+      // x <- S^-1 x with the factors in G:  forward L y = x,  backward L^T z = D^-1 y
+      auto ldl_solve = [&](double (&x)[TD]) {
 #pragma unroll
-      for (int i = 0; i < MR; ++i) {
-        double s = rv[i];
+        for (int i = 0; i < MR; ++i) {
+          double s = x[i];
 #pragma unroll
-        for (int j = 0; j < i; ++j) s = fma(-G[tri(i, j)], rv[j], s);
-        rv[i] = s;
-      }
-      // backward L^T z = D^-1 y
+          for (int j = 0; j < i; ++j) s = fma(-G[tri(i, j)], x[j], s);
+          x[i] = s;
+        }
 #pragma unroll
-      for (int i = MR - 1; i >= 0; --i) {
-        double s = rv[i] * G[tri(i, i)];
+        for (int i = MR - 1; i >= 0; --i) {
+          double s = x[i] * G[tri(i, i)];
 #pragma unroll
-        for (int j = i + 1; j < MR; ++j) s = fma(-G[tri(j, i)], rv[j], s);
-        rv[i] = s;
-      }
+          for (int j = i + 1; j < MR; ++j) s = fma(-G[tri(j, i)], x[j], s);
+          x[i] = s;
+        }
+      };
+      ldl_solve(rv);
       // v = Y z (Legendre bubble coefficients), w_{0,1} = d - C v
       double C0[TD], C1[TD];
       if (any_slow) {
@@ -444,16 +450,69 @@ __device__ __forceinline__ void enhance_small_body_cheb(const EnhanceArgs& p, co
         }
       }
       double w0 = d0, w1 = d1;
+      auto to_legendre = [&]() {           // v = Y z,  w_{0,1} = d - C v
+        w0 = d0;
+        w1 = d1;
 #pragma unroll
-      for (int j = 0; j < MR; ++j) {
-        double v = 0.0;
+        for (int j = 0; j < MR; ++j) {
+          double v = 0.0;
 #pragma unroll
-        for (int i = j; i < MR; i += 2) v = fma(cheb::kY[j][i], rv[i], v);
-        w[j + 2] = v;
-        w0 = fma(-C0[j], v, w0);
-        w1 = fma(-C1[j], v, w1);
-        ok = ok && (fabs(v) < 1.0e300);
+          for (int i = j; i < MR; i += 2) v = fma(cheb::kY[j][i], rv[i], v);
+          w[j + 2] = v;
+          w0 = fma(-C0[j], v, w0);
+          w1 = fma(-C1[j], v, w1);
+        }
+      };
+      to_legendre();
+      // ---- NEAR-SQUARE REGIME (about as many equispaced points as bubble coefficients: the normal
+      // equations lose up to ten digits): p.refine steps of the CORRECTED SEMI-NORMAL
+      // equations -- the residual of S2 z = rhs2 taken through the ROWS,
+      //     rho_i = sum_k T_i(t_k) (phi2_k - 2 sum_j z_j T_j(t_k))          (collocation part)
+      //           + eps2 sum_j Y[j][i] (C0_j w_0 + C1_j w_1 - v_j)          (ridge part = -eps2 Y^T grad_v |w|^2/2)
+      // never through the Gram matrix, solved with the factors already in G:  z += S^-1 rho.
+      // What solve4_kernel<2> + residual_kernel do above M = 22 (round 2), here per lane (round 3).
+      // A launch parameter (uniform); instantiated from M = 14 up (below, the normal equations are at
+      // 2e-17 from n = M - 2 on) as a kernel of its own.
+      if constexpr (REFINE) {
+        for (int it = 0; it < p.refine; ++it) {
+          double rho[TD];
+#pragma unroll
+          for (int i = 0; i < MR; ++i) {
+            double s = 0.0;
+#pragma unroll
+            for (int j = (i & 1); j <= i; j += 2) s = fma(cheb::kY[j][i], fma(C0[j], w0, fma(C1[j], w1, -w[j + 2])), s);
+            rho[i] = eps2 * s;
+          }
+#pragma nounroll
+          for (int k = 0; k < n; ++k) {
+            const double xk = (k == n - 1) ? b : (double)k * step + a;
+            const double tk = dm.off + dm.scl * xk;
+            double phi2;
+            if constexpr (RHS == LSSVR_RHS_SIN) phi2 = kappa * sin_tab(p.rhs_omega * xk, p.trig);
+            else phi2 = p.rhs_values[ec * p.tab_es + k * p.tab_ps] * fscale;
+            double T[TD];
+            T[0] = 1.0;
+            if constexpr (MR > 1) T[1] = tk;
+            const double tt = tk + tk;
+            double Tz = rv[0];
+            if constexpr (MR > 1) Tz = fma(tk, rv[1], Tz);
+#pragma unroll
+            for (int d = 2; d < MR; ++d) {
+              T[d] = fma(tt, T[d - 1], -T[d - 2]);
+              Tz = fma(T[d], rv[d], Tz);
+            }
+            const double ek = fma(-2.0, Tz, phi2);
+#pragma unroll
+            for (int d = 0; d < MR; ++d) rho[d] = fma(T[d], ek, rho[d]);
+          }
+          ldl_solve(rho);
+#pragma unroll
+          for (int i = 0; i < MR; ++i) rv[i] += rho[i];
+          to_legendre();
+        }
       }
+#pragma unroll
+      for (int j = 0; j < MR; ++j) ok = ok && (fabs(w[j + 2]) < 1.0e300);
       w[0] = w0;
       w[1] = w1;
       ok = ok && (fabs(w0) < 1.0e300) && (fabs(w1) < 1.0e300);

@@ -382,6 +382,13 @@ __global__ __launch_bounds__(kBlock, MINW) void enhance_small_kernel(EnhanceArgs
   }
 }
 
+// The Poisson lane kernel with the near-square refinement loop (launches with p.refine > 0 only)
+template <int M, int RHS>
+__global__ __launch_bounds__(kBlock) void enhance_small_refine_kernel(EnhanceArgs p) {
+  __shared__ double tile[(kBlock / 64) * kChebTilePerWave<M, RHS>];
+  enhance_small_body_cheb<M, RHS, true>(p, blockIdx.x, tile);
+}
+
 // One launch for a whole step of the hot path on one mesh: blocks [0, eblocks) run the
 // per-element enhancement, the remaining blocks the element-local P1 assembly (one thread
 // per node).  The two halves share nothing but the node array, so fusing them only removes
@@ -423,6 +430,9 @@ static hipError_t launch_small(const EnhanceArgs& a, hipStream_t s, const Launch
   // (An occupancy-4 build -- __launch_bounds__(kBlock, 4): 128 VGPRs, a few spills -- used to take
   // over above 2e5 elements; since the Chebyshev-moment body needs 136 VGPRs it loses: 406 against
   // 388 us at 1e7 elements, 41.9 against 41.3 at 1e6, same run.)
+  if constexpr (!VC && M >= kRefineMinM) {
+    if (a.refine > 0) return launch(enhance_small_refine_kernel<M, RHS>, dim3(blocks), dim3(kBlock), s, o, a);
+  }
   return launch(enhance_small_kernel<M, RHS, VC, 1>, dim3(blocks), dim3(kBlock), s, o, a);
 }
 

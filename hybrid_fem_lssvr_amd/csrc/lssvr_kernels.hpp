@@ -18,6 +18,7 @@ struct EnhanceArgs {
   double gxmin, gxmax, bc_left, bc_right, gamma;
   double inv_gamma;         // 1 / gamma, rounded on the host (the scalar-gamma path divides nowhere)
   int M, n;
+  int refine;               // lane kernel, Poisson rows: refinement steps of the near-square regime (0: none)
   int rhs_id;
   double rhs_amp, rhs_omega;
   const double* rhs_values;
@@ -96,6 +97,7 @@ hipError_t enhance_large(const EnhanceArgs& a, hipStream_t s, const LaunchOpts* 
 // Poisson rows, any M <= 33: Chebyshev-moment Gram (enhance_large_cheb.hip, enhance_large_parity.hip): a
 // sequence of kernels with a workspace of enhance_moment_ws_bytes(ne, M, n) bytes in between
 int enhance_refine_steps(int M, int n);
+int enhance_small_refine_steps(int M, int n);   // the lane kernel's rule (M <= kSmallMaxM)
 int64_t enhance_moment_ws_bytes(int64_t ne, int M, int n);
 hipError_t enhance_large_split(const EnhanceArgs& a, void* work, hipStream_t s, const LaunchOpts* o = nullptr);
 // the well-posed regime (n >= 2 (M-2)) of the two-kernel path: parity-split solve (enhance_large_parity.hip)

@@ -541,3 +541,46 @@ def test_in_kernel_sin_per_point_branch(dev, note, x0, h):
         err = orc.rel_l2_coef(W1[sel], tr).max()
         note("per-point sin x0=%.1e h=%g vs 60-digit minimiser" % (x0, h), err, 1e-14)
         assert err <= 1e-14, err                # measured 1.0e-16 .. 1.3e-15
+
+
+# (M, n, h): about as many equispaced points as bubble coefficients, M <= 22 -- the lane kernel's own
+# refinement (round 3; measured without it: 2.0e-12 at (22, 20, 0.5), 7e-14 at (22, 21, 0.5) and
+# (20, 18, 0.5), 1.3e-14 at (22, 20, 1/12); with it <= 5.5e-16 everywhere)
+LANE_NEAR_SQUARE = [(22, 20, 0.5), (22, 21, 0.5), (22, 24, 0.5), (20, 18, 0.5), (18, 16, 0.5), (16, 14, 0.5),
+                    (14, 12, 0.5), (22, 20, 1.0 / 12), (20, 18, 1.0 / 12), (15, 13, 0.25)]
+
+
+@pytest.mark.skipif(not cf.HAVE_MP, reason="mpmath missing")
+@pytest.mark.parametrize("M,n,h", LANE_NEAR_SQUARE)
+def test_lane_kernel_near_square_refinement(dev, note, M, n, h):
+    """n ~ M - 2 below M = 23: 1-2 steps of the corrected semi-normal equations inside the lane kernel
+    (enhance_small_refine_kernel: residual through the rows, the factors re-used) bring the result
+    to the 60-digit minimiser at the same bar as everywhere else -- in-kernel and tabulated (both
+    layouts) right-hand sides, the fused step, a subset launch."""
+    import torch
+    from hybrid_fem_lssvr_amd import ops
+    ne = 150
+    rng = np.random.default_rng(M * 100 + n)
+    nodes = -1.0 + h * np.arange(ne + 1)
+    values = np.sin(np.pi * nodes) + 0.01 * rng.standard_normal(ne + 1)
+    gd = (nodes[0], nodes[-1])
+    x, u = _t(nodes, dev), _t(values, dev)
+    sel = [0, 1, 63, 64, ne - 1]
+    tr = cf.truth_all(nodes, values, M, 1e4, n, orc.poisson_rhs, gd, sel)
+    W, st = ops.enhance(x, u, M, 1e4, n, global_domain=gd)
+    xc = ops.colloc_points(x, n)
+    f = _t(orc.poisson_rhs(xc.cpu().numpy()), dev)
+    W2, _ = ops.enhance(x, u, M, 1e4, n, global_domain=gd, rhs_values=f)
+    W3, _ = ops.enhance(x, u, M, 1e4, n, global_domain=gd, rhs_values=f.t().contiguous(), point_major=True)
+    plan = ops.StepPlan(x, u, M, 1e4, n, global_domain=gd)
+    W4, _ = plan.launch()
+    W5 = torch.zeros((ne, M), dtype=torch.float64, device=dev)
+    ops.enhance_subset(x, u, M, 1e4, n, W5, elem_ids=_t(np.array(sel, dtype=np.int64), dev), global_domain=gd)
+    torch.cuda.synchronize()
+    assert int(st.sum()) == 0
+    worst = 0.0
+    for Wx in (W, W2, W3, W4, W5):
+        worst = max(worst, orc.rel_l2_coef(Wx.cpu().numpy()[sel], tr).max())
+    note("lane near-square M=%d n=%d h=%.3g vs 60-digit minimiser" % (M, n, h), worst, 5e-15)
+    assert worst <= 5e-15, worst
+    assert torch.equal(W2, W3) and torch.equal(W, W4)
