@@ -90,15 +90,19 @@ def _to_dev(a, device):
     return torch.as_tensor(np.ascontiguousarray(np.asarray(a, dtype=np.float64)), device=device)
 
 
-def _rhs_mode(rhs, x_dev, n_colloc):
-    """(rhs=(amp, omega) | None, rhs_values | None) for ops.enhance."""
+def _rhs_mode(rhs, x_dev, n_colloc, M=None):
+    """Keyword arguments of ops.enhance for the right-hand side: ``rhs=(amp, omega)`` for the named
+    f, else the callable (Dual.py:20 ``rhs_func``) tabulated on the host at np.linspace's points
+    (Dual.py:40) -- POINT-major (``t[k, e]``) for the lane-per-element kernels (M <= 22), which read
+    that layout at full HBM rate, element-major otherwise; the values are the same either way."""
     if isinstance(rhs, SinRHS):
-        return (rhs.amp, rhs.omega), None
-    xc = ops.colloc_points(x_dev, n_colloc)                    # np.linspace per element
+        return dict(rhs=(rhs.amp, rhs.omega))
+    pm = M is not None and int(M) <= 22
+    xc = ops.colloc_points(x_dev, n_colloc, point_major=pm)    # np.linspace per element
     f = np.asarray(rhs(xc.cpu().numpy()), dtype=np.float64)
     if f.shape != tuple(xc.shape):
         f = np.broadcast_to(f, tuple(xc.shape))
-    return None, _to_dev(f, x_dev.device)
+    return dict(rhs_values=_to_dev(f, x_dev.device), point_major=pm)
 
 
 def _enhance(x, u, M, gamma, n_colloc, *, global_domain, bc, solver, uniform_rtol=1e-9, **kw):
@@ -189,8 +193,7 @@ def enhance_elements(mesh, nodal_values, M, gamma, *, n_colloc=12, rhs=poisson_r
         raise ValueError("nodal_values must have one value per mesh node")
     if global_domain is None:
         global_domain = (float(m.nodes[0]), float(m.nodes[-1]))
-    pr, fv = _rhs_mode(rhs, x, n_colloc)
-    kw = dict(rhs=pr) if pr is not None else dict(rhs_values=fv)
+    kw = _rhs_mode(rhs, x, n_colloc, M)
     W, st = _enhance(x, u, int(M), float(gamma), int(n_colloc), global_domain=global_domain,
                      bc=bc, solver=solver, **kw)
     return EnhancedSolution(x, W, st)
@@ -260,8 +263,7 @@ def lssvr_primal(rhs_func, domain_range, u_xmin, u_xmax, M, gamma,
     # the kernel derives the flags from the element's global index (Dual.py:150-151)
     off = 0 if is_left_boundary else 1
     ne_global = off + 1 if is_right_boundary else off + 2
-    pr, fv = _rhs_mode(rhs_func, x, n_colloc)
-    kw = dict(rhs=pr) if pr is not None else dict(rhs_values=fv)
+    kw = _rhs_mode(rhs_func, x, n_colloc, M)
     W, st = ops.enhance(x, u, int(M), float(gamma), int(n_colloc), elem_offset=off,
                         ne_global=ne_global,
                         global_domain=(float(global_domain_range[0]), float(global_domain_range[1])),
@@ -352,8 +354,7 @@ class FEMLSSVRPrimalSolver:
         if x is None or x.numel() != nodes.size or not np.array_equal(x.cpu().numpy(), nodes):
             x = _to_dev(nodes, dev)
         u = _to_dev(self.fem_values, dev)       # the attribute is authoritative (may be user-set)
-        pr, fv = _rhs_mode(self.rhs, x, self.n_colloc)
-        kw = dict(rhs=pr) if pr is not None else dict(rhs_values=fv)
+        kw = _rhs_mode(self.rhs, x, self.n_colloc, self.lssvr_M)
         W, st = _enhance(x, u, int(self.lssvr_M), float(self.lssvr_gamma), int(self.n_colloc),
                          global_domain=(float(self.global_domain[0]), float(self.global_domain[1])),
                          bc=(main_boundary_condition_left(self.global_domain[0]),

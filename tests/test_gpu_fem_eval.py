@@ -422,3 +422,25 @@ def test_eval_error_norms_on_device(dev):
     ops.eval_error(s.enhanced.nodes, s.enhanced.W, xq[:100].contiguous(), out=acc)
     ops.eval_error(s.enhanced.nodes, s.enhanced.W, xq[100:].contiguous(), out=acc)
     assert np.allclose(acc.cpu().numpy(), out, rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("M,n", [(9, 16), (22, 44), (33, 64)])
+def test_facade_callable_rhs_is_tabulated_in_the_kernels_layout(dev, M, n):
+    """An arbitrary ``rhs_func`` (Dual.py:20, 157) reaches the kernels as a table at np.linspace's points:
+    point-major for the lane kernels (M <= 22), element-major above -- same values, so the result equals the
+    named in-kernel f to rounding and (M <= 22) the element-major call bit for bit."""
+    import torch
+    import hybrid_fem_lssvr_amd as pkg
+    from hybrid_fem_lssvr_amd import ops
+    ne = 333
+    nodes = np.linspace(-1, 1, ne + 1)
+    values = orc.fem_p1_solve(nodes)
+    named = pkg.enhance_elements(nodes, values, M, 1e4, n_colloc=n)
+    tabd = pkg.enhance_elements(nodes, values, M, 1e4, n_colloc=n, rhs=lambda x: np.pi ** 2 * np.sin(np.pi * x))
+    assert named.n_fallback == 0 and tabd.n_fallback == 0
+    assert orc.rel_l2_coef(tabd.W.cpu().numpy(), named.W.cpu().numpy()).max() <= 1e-13
+    x, u = _t(nodes, dev), _t(values, dev)
+    f_em = _t(orc.poisson_rhs(ops.colloc_points(x, n).cpu().numpy()), dev)
+    W_em, _ = ops.enhance(x, u, M, 1e4, n, global_domain=(-1.0, 1.0), rhs_values=f_em)
+    torch.cuda.synchronize()
+    assert torch.equal(W_em, tabd.W)
