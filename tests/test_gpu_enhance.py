@@ -584,3 +584,49 @@ def test_lane_kernel_near_square_refinement(dev, note, M, n, h):
     note("lane near-square M=%d n=%d h=%.3g vs 60-digit minimiser" % (M, n, h), worst, 5e-15)
     assert worst <= 5e-15, worst
     assert torch.equal(W2, W3) and torch.equal(W, W4)
+
+
+@pytest.mark.skipif(not cf.HAVE_MP, reason="mpmath missing")
+@pytest.mark.parametrize("seed", [31, 32, 33])
+def test_random_parity_sweep(dev, note, seed):
+    """scripts/stress_parity.py as a driver-run test: 40 random (M in [2, 33], n in [2, 80], gamma in
+    [1e-2, 1e8], h in [1e-7, 10], x0 up to 1e6) per seed on non-uniform 12-element meshes, every route
+    the default solver can take (lane kernel incl. its cold paths and near-square refinement, moment /
+    parity-split / refined two-kernel path, dual solver below the rank boundary), each against the
+    60-digit minimiser of the reference's QP (Dual.py:46-78) at the same float64 abscissae.
+    Bar: 1e-13 where gamma scl^4 >= 1 and h <= 1 (every regime a mesh refinement produces); coarse
+    elements with a tiny penalty are the problem's own cond(A) u (round 2's sweep: worst 2e-12): 5e-12."""
+    import torch
+    from hybrid_fem_lssvr_amd import ops
+    rng = np.random.default_rng(seed)
+    worst_tight, worst_loose = 0.0, 0.0
+    for _ in range(40):
+        M = int(rng.integers(2, 34))
+        n = int(rng.integers(2, 81))
+        if n < M - 2 and n > 64:
+            continue
+        gamma = 10.0 ** rng.uniform(-2, 8)
+        h = 10.0 ** rng.uniform(-7, 1)
+        x0 = rng.choice([-1, 1]) * 10.0 ** rng.uniform(-1, 6) * rng.choice([0, 1, 1])
+        ne = 12
+        nodes = x0 + h * np.cumsum(np.concatenate([[0.0], rng.uniform(0.5, 1.5, ne)]))
+        if not np.all(np.diff(nodes) > 0):
+            continue
+        values = np.sin(np.pi * nodes) + 0.1 * rng.standard_normal(ne + 1)
+        gd = (nodes[0], nodes[-1])
+        W, st = ops.enhance(_t(nodes, dev), _t(values, dev), M, gamma, n, global_domain=gd)
+        torch.cuda.synchronize()
+        W, st = W.cpu().numpy(), st.cpu().numpy()
+        sel = [0, 5, 11]
+        assert np.all(st[sel] == 0), (M, n, gamma, h, x0)
+        tr = cf.truth_all(nodes, values, M, gamma, n, orc.poisson_rhs, gd, sel)
+        err = float(orc.rel_l2_coef(W[sel], tr).max())
+        well_posed = gamma * (2.0 / np.diff(nodes).max()) ** 4 >= 1.0 and np.diff(nodes).max() <= 1.0
+        if well_posed:
+            worst_tight = max(worst_tight, err)
+            assert err <= 1e-13, (err, M, n, gamma, h, x0)
+        else:
+            worst_loose = max(worst_loose, err)
+            assert err <= 5e-12, (err, M, n, gamma, h, x0)
+    note("random sweep seed %d: worst, well-posed regime" % seed, worst_tight, 1e-13)
+    note("random sweep seed %d: worst, coarse / tiny-penalty regime" % seed, worst_loose, 5e-12)
