@@ -1118,9 +1118,11 @@ def run_single(args, D, M, n, ne_glob, lo, hi, dev, cpu_res, use_dist):
     k_dur = max(k_avg, 1e-9)
     ach_tflops = flops * ne_loc / k_dur / 1e12
     if dual:
-        kernel_name, bound = "enhance_dual_kernel", "fp64-valu"
+        big = max(M, n) > 32
+        kernel_name, bound = ("enhance_dual_w64_kernel" if big else "enhance_dual_kernel"), "fp64-valu"
         pipe = ("FP64 vector FMA only (row per lane: Gram by scalar FMAs, partial-pivot LU with the pivot row "
-                "through LDS, <= 3 safeguarded refinement steps); no MFMA is issued")
+                + ("read out of the pivot lane by v_readlane, two waves per SIMD" if big else "through LDS")
+                + ", <= 3 safeguarded refinement steps); no MFMA is issued")
         solver_lbl = "dual Gram form (K + I/gamma) alpha = y: boundary block pivot, Jacobi equilibration, partial-pivot LU"
     elif M <= 22:
         kernel_name, bound = "enhance_small_kernel<M=%d>" % M, "fp64-valu"

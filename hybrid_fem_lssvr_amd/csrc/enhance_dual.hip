@@ -32,6 +32,7 @@
 // Mapping: LPE = 16 / 32 / 64 lanes per element (the smallest that holds max(n, M)), 64 / LPE
 // elements per wave, one wave per workgroup, wave-private LDS.  Lane r of an element is collocation
 // row r: it keeps its row of A' (M values) and its row of K (n values) in registers.
+#include <cstdlib>
 #include "lssvr_device.hpp"
 #include "lssvr_kernels.hpp"
 #include "lssvr_wave.hpp"
@@ -43,7 +44,10 @@ namespace {
 
 constexpr int kDualMaxM = 33;
 constexpr int kDualMaxN = 64;
-constexpr int kRefine = 3;
+#ifndef LSSVR_DUAL_REFINE
+#define LSSVR_DUAL_REFINE 3      // (measurement builds lower it)
+#endif
+constexpr int kRefine = LSSVR_DUAL_REFINE;
 
 // three-term recurrence coefficients as compile-time literals (the rows are built once per
 // element in straight-line code, so literals cost no long-lived registers):
@@ -416,6 +420,369 @@ __global__ __launch_bounds__(64) void enhance_dual_kernel(EnhanceArgs p, int nre
   }
 }
 
+// =============================================================================================
+// n > 32 or M > 32 (BASELINE config 4: 64 points), round 3: one element per wave, TWO waves per SIMD.
+// The generic kernel above at LPE = 64 holds a row of K (128 VGPRs) AND a row of A' (72) per lane, sends
+// the pivot row through LDS and searches the pivot with twelve 64-bit ds_bpermute: 256 VGPRs + 136 AGPRs,
+// one wave per SIMD, 23 400 instructions per element at the lone-wave issue rate (one instruction per
+// ~9 cycles): 12.4 ms per 1e5 elements.  Same algorithm here -- block-pivoted boundary rows, Jacobi
+// equilibration, LU with PARTIAL PIVOTING, safeguarded refinement with the compensated operator residual --
+// arranged for the register file:
+//   * the rows of A' live in LDS (row stride 33, odd: conflict-free for a lane reading its own row and for
+//     a lane reading a column); the Gram takes four columns of A' at a time against 64 accumulators;
+//   * the pivot row never travels: every lane reads it out of lane P with v_readlane (SGPR operands of the
+//     FMA), no LDS round trip and no wave sync inside an elimination step (measured alternatives, DESIGN
+//     section 3.2b: the row through LDS with the publish overlapped by the next pivot search, 6.0 ms
+//     against 5.2 -- with 256 registers only three broadcast reads are in flight per wave);
+//   * pivot search by a DPP max-reduction on 32-bit keys (exponent + 19 mantissa bits + lane);
+//   * <= 256 registers, so two waves share a SIMD and fill each other's issue gaps; 19 KB of LDS per wave,
+//     eight waves per CU.
+// (Measured and rejected in between, DESIGN section 3.2b: one element per WORKGROUP of four waves, 16 columns
+// per wave -- 14.2 ms with one barrier per elimination step, 14.6 ms blocked by column panel; the chains of
+// the substitutions and the residual are serial across the waves and the barriers couple their issue.)
+// =============================================================================================
+namespace {
+// maximum of a 32-bit key over the 64 lanes, as a wave-uniform value: four DPP row shifts leave the
+// maximum of every 16-lane row in its lane 15; the four row results are combined on the scalar unit.
+// ~12 instructions and no LDS round trip (the 64-bit shuffle reduction above: 12 ds_bpermute).
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true));   // row_shr:1
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true));   // row_shr:2
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true));   // row_shr:4
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true));   // row_shr:8
+  const unsigned r0 = __builtin_amdgcn_readlane(v, 15), r1 = __builtin_amdgcn_readlane(v, 31);
+  const unsigned r2 = __builtin_amdgcn_readlane(v, 47), r3 = __builtin_amdgcn_readlane(v, 63);
+  return max(max(r0, r1), max(r2, r3));
+}
+constexpr int kW64MP = 36;             // padded number of Legendre coefficients in the row build (M <= 33)
+constexpr int kW64MU = kDualMaxM;      // columns of A' that can be non-zero
+constexpr int kW64ZS = 33;             // row stride of A' in LDS
+}  // namespace
+
+template <int RHS, bool VC>
+__global__ __launch_bounds__(64, 2) void enhance_dual_w64_kernel(EnhanceArgs p, int nrefine) {
+  constexpr int MP = kW64MP, MU = kW64MU, ZS = kW64ZS, N = 64;
+  __shared__ double Zs[N * ZS];
+  __shared__ double LaS[MP], LbS[MP];
+  __shared__ double Ds[N];              // equilibration scales
+  __shared__ double Bs[N];              // broadcast operand of A'^T dl
+  __shared__ double Ws[MP];             // carried w for the residual
+  const int l = threadIdx.x & 63;
+  const int M = p.M, n = p.n;
+  const int64_t e = blockIdx.x;                     // grid = ne waves
+  const double a = p.x[e];
+  const double b = p.x[e + 1];
+  const int64_t eg = e + p.elem_offset;
+  const double gl = (eg == 0 && a == p.gxmin) ? p.bc_left : p.u[e];
+  const double gr = (eg == p.ne_global - 1 && b == p.gxmax) ? p.bc_right : p.u[e + 1];
+  const double gamma = p.gamma_values ? p.gamma_values[e] : p.gamma;
+  const DomainMap dm = map_params(a, b);
+  const double step = dm.oldlen / (double)(n - 1);
+  const double scl2 = dm.scl * dm.scl;
+  const double inv_scl2 = rcp_newton(scl2);
+  const double eps = rcp_newton(gamma * (scl2 * scl2));
+  const bool is_pt = l < n;
+
+  // ---- boundary rows, Q = B B^T, row l of A, projection, f' -> LDS ---------------------------------
+  double qi00, qi01, qi11, g0, g1, fp;
+  {
+    const double ta = dm.off + dm.scl * a;
+    const double tb_ = dm.off + dm.scl * b;
+    if (l < 2) {
+      const double t = l == 0 ? ta : tb_;
+      double* const dst = l == 0 ? LaS : LbS;
+      double Lm2 = 1.0, Lm1 = t;
+      dst[0] = 1.0;
+      dst[1] = (M > 1) ? t : 0.0;
+#pragma unroll
+      for (int pp = 2; pp < MP; ++pp) {
+        const double Lp = fma(alL(pp) * t, Lm1, -(beL(pp) * Lm2));
+        dst[pp] = (pp < M) ? Lp : 0.0;
+        Lm2 = Lm1;
+        Lm1 = Lp;
+      }
+    }
+    wave_lds_sync();
+    double q00 = 0.0, q01 = 0.0, q11 = 0.0;
+#pragma unroll
+    for (int pp = 0; pp < MP; ++pp) {
+      const double la = LaS[pp], lb = LbS[pp];
+      q00 = fma(la, la, q00);
+      q01 = fma(la, lb, q01);
+      q11 = fma(lb, lb, q11);
+    }
+    const double qdet = rcp_newton(fma(q00, q11, -(q01 * q01)));
+    qi00 = q11 * qdet;
+    qi01 = -q01 * qdet;
+    qi11 = q00 * qdet;
+    g0 = fma(qi00, gl, qi01 * gr);
+    g1 = fma(qi01, gl, qi11 * gr);
+    const double xk = (is_pt && l == n - 1) ? b : (double)(is_pt ? l : 0) * step + a;
+    const double tk = dm.off + dm.scl * xk;
+    double ftil = 0.0;
+    if (is_pt) {
+      double fk;
+      if constexpr (RHS == LSSVR_RHS_SIN) fk = p.rhs_amp * sin_reduced(p.rhs_omega * xk);
+      else fk = p.rhs_values[e * p.tab_es + l * p.tab_ps];
+      ftil = fk * inv_scl2;
+    }
+    double arow[MP];
+    {
+      const double sgn = is_pt ? -1.0 : 0.0;
+      double ak = 1.0, bk = 0.0;
+      if constexpr (VC) {
+        if (is_pt) {
+          ak = p.a_values[e * p.tab_es + l * p.tab_ps];
+          bk = p.da_values[e * p.tab_es + l * p.tab_ps] * (0.5 * dm.oldlen);
+        }
+      }
+      double q2 = 0.0, q1 = 0.0, r2 = 0.0, r1 = 0.0;
+#pragma unroll
+      for (int pp = 0; pp < MP; ++pp) {
+        double d2 = 0.0, d1 = 0.0;
+        if (pp >= 2) {
+          const int m = pp - 2;
+          d2 = (m == 0) ? 3.0 : (m == 1) ? 15.0 * tk : fma(al2(m) * tk, q1, -(be2(m) * q2));
+          q2 = q1;
+          q1 = d2;
+        }
+        if constexpr (VC) {
+          if (pp >= 1) {
+            const int m = pp - 1;
+            d1 = (m == 0) ? 1.0 : (m == 1) ? 3.0 * tk : fma(al1(m) * tk, r1, -(be1(m) * r2));
+            r2 = r1;
+            r1 = d1;
+          }
+        }
+        const double v = VC ? fma(ak, d2, bk * d1) : d2;
+        arow[pp] = (pp < M) ? sgn * v : 0.0;
+      }
+    }
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int pp = 0; pp < MP; ++pp) {
+      s0 = fma(arow[pp], LaS[pp], s0);
+      s1 = fma(arow[pp], LbS[pp], s1);
+    }
+    const double c0 = fma(qi00, s0, qi01 * s1), c1 = fma(qi01, s0, qi11 * s1);
+#pragma unroll
+    for (int pp = 0; pp < MU; ++pp) Zs[l * ZS + pp] = fma(-c1, LbS[pp], fma(-c0, LaS[pp], arow[pp]));   // (columns >= M <= 33: zero)
+    fp = ftil - fma(s0, g0, s1 * g1);
+  }
+  wave_lds_sync();
+
+  // ---- K = A' A'^T, row l: four columns of A' at a time against all 64 rows -----------------------------
+  // krow[c] += sum over the chunk of A'[l][pp] A'[c][pp]: the lane's own four values in registers, the other
+  // operand by broadcast reads; 64 independent accumulation chains (one per column) keep the FP64 pipe busy
+  // and every entry still sums its products in the order pp = 0, 1, 2, ...  Columns are skipped in blocks of
+  // eight beyond n (rows >= n of A' are zero anyway).
+  double krow[N];
+  double kdiag = 0.0;
+  {
+    int ns = n;
+    asm volatile("" : "+s"(ns));
+#pragma unroll
+    for (int c = 0; c < N; ++c) krow[c] = 0.0;
+    constexpr int kQ = 4;
+#pragma unroll
+    for (int p0 = 0; p0 < MU; p0 += kQ) {
+      double ar[kQ];
+#pragma unroll
+      for (int q = 0; q < kQ; ++q)
+        if (p0 + q < MU) {
+          ar[q] = Zs[l * ZS + p0 + q];
+          kdiag = fma(ar[q], ar[q], kdiag);
+        }
+#pragma unroll
+      for (int c0 = 0; c0 < N; c0 += 8) {
+        if (c0 < ns) {
+#pragma unroll
+          for (int c = c0; c < c0 + 8; ++c) {
+            const double* __restrict__ zc = Zs + c * ZS;
+#pragma unroll
+            for (int q = 0; q < kQ; ++q)
+              if (p0 + q < MU) krow[c] = fma(ar[q], zc[p0 + q], krow[c]);
+          }
+        }
+      }
+    }
+  }
+  // (K + eps I), Jacobi equilibration (kdiag is K_ll with the rounding of krow[l]: same products, same order)
+  const double dr = is_pt ? rsqrt_newton(kdiag + eps) : 1.0;
+  Ds[l] = dr;
+  wave_lds_sync();
+#pragma unroll
+  for (int c = 0; c < N; ++c) {
+    const double kc = krow[c] + ((c == l) ? eps : 0.0);
+    krow[c] = (c < n && is_pt) ? kc * dr * Ds[c] : ((c == l) ? 1.0 : 0.0);
+  }
+
+  // ---- LU with partial pivoting, rhs carried; refinement re-uses the factors ---------------------------
+  // pivstep: step at which this row was the pivot (-1: still active).  After the elimination the row holds
+  // U[pivstep][c] for c >= pivstep and the multipliers L for c < pivstep.  Only the STEPS are guarded by n
+  // (columns >= n are exact zeros in every row).
+  int pivstep = is_pt ? -1 : 0x7fff;
+  double rinv_own = 1.0;               // 1 / pivot of the step at which this row was the pivot
+  int pvec = 0;                        // lane j keeps the pivot lane of step j
+  double y = dr * fp;
+  {
+    int ns = n;
+    asm volatile("" : "+s"(ns));
+    static_for<0, N>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      if (j < ns) {
+        // pivot search on the top 31 bits of |a_lj| (exponent + 19 mantissa bits), lane in the low six
+        const bool active = pivstep < 0;
+        const unsigned hi = (unsigned)(__builtin_bit_cast(unsigned long long, fabs(krow[j])) >> 32);
+        const unsigned key = active ? (0x80000000u | ((hi >> 1) & ~63u) | (unsigned)l) : 0u;
+        const int P = (int)(wave_max_u32(key) & 63u);
+        const double rinv = rcp_newton(readlane_f64(krow[j], P));
+        if (l == P) {
+          pivstep = j;
+          rinv_own = rinv;
+        }
+        if (l == j) pvec = P;
+        const bool act = pivstep < 0;
+        const double m = act ? krow[j] * rinv : 0.0;
+        if (act) krow[j] = m;
+        // the pivot row, read out of lane P in batches of kB columns (independent SGPR pairs: the two wait
+        // states between a v_readlane and the FMA that takes its result are filled by the next reads)
+        constexpr int kB = 6;
+        const double nm = -m;
+#pragma unroll
+        for (int c0 = j + 1; c0 < N; c0 += kB) {
+          double u[kB];
+#pragma unroll
+          for (int q = 0; q < kB; ++q)
+            if (c0 + q < N) u[q] = readlane_f64(krow[c0 + q], P);
+#pragma unroll
+          for (int q = 0; q < kB; ++q)
+            if (c0 + q < N) krow[c0 + q] = fma(nm, u[q], krow[c0 + q]);
+        }
+        y = fma(nm, readlane_f64(y, P), y);
+      }
+    });
+  }
+  // forward substitution with the stored multipliers (refinement): v -> L^-1 P v, row-indexed
+  auto forward = [&](double v) -> double {
+    int ns = n;
+    asm volatile("" : "+s"(ns));
+    static_for<0, N>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      if (j < ns) {
+        const int P = __builtin_amdgcn_readlane(pvec, j);
+        const double vj = readlane_f64(v, P);
+        const double m = (pivstep > j) ? krow[j] : 0.0;   // (padding rows: krow[j] == 0 for j < n)
+        v = fma(-m, vj, v);
+      }
+    });
+    return v;
+  };
+  // back substitution U x = v; returns x_l (column-indexed: lane l gets the unknown of column l)
+  auto backward = [&](double v) -> double {
+    double xl = 0.0;
+    int ns = n;
+    asm volatile("" : "+s"(ns));
+    static_for<0, N>([&](auto jc) {
+      constexpr int j = N - 1 - decltype(jc)::value;
+      if (j < ns) {
+        const int P = __builtin_amdgcn_readlane(pvec, j);
+        const double xj = readlane_f64(v * rinv_own, P);              // lane P: pivstep == j
+        if (l == j) xl = xj;
+        const double u = (pivstep < j) ? krow[j] : 0.0;
+        v = fma(-u, xj, v);
+      }
+    });
+    return xl;
+  };
+  // lane p < 33: sum_r A'[r][p] dl_r (column p of A' in LDS: consecutive lanes, consecutive addresses)
+  auto at_times = [&](double dl) -> double {
+    wave_lds_sync();
+    Bs[l] = dl;
+    wave_lds_sync();
+    const int pc = l < MU ? l : 0;
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int c = 0; c < N; c += 2) {                                  // (padding rows are zero)
+      a0 = fma(Zs[c * ZS + pc], Bs[c], a0);
+      a1 = fma(Zs[(c + 1) * ZS + pc], Bs[c + 1], a1);
+    }
+    return l < MU ? a0 + a1 : 0.0;
+  };
+  // equilibrated residual of the pair (lam, w) in operator form, and its squared norm:
+  // f' - eps lam - A' w in compensated (double-double) arithmetic (see the generic kernel)
+  auto residual = [&](double lam_, double wv_, double& nrm_) -> double {
+    wave_lds_sync();
+    if (l < MP) Ws[l] = wv_;
+    wave_lds_sync();
+    double hi = fp, lo = 0.0;
+    auto acc = [&](double x, double yv) {          // (hi, lo) += x * y exactly
+      const double pr_ = x * yv;
+      const double pe = fma(x, yv, -pr_);
+      const double t = hi + pr_;
+      const double bb = t - hi;
+      lo += ((hi - (t - bb)) + (pr_ - bb)) + pe;
+      hi = t;
+    };
+    acc(-eps, lam_);
+#pragma unroll
+    for (int pp = 0; pp < MU; ++pp) acc(-Zs[l * ZS + pp], Ws[pp]);
+    double r_ = hi + lo;
+    r_ = is_pt ? dr * r_ : 0.0;
+    nrm_ = group_sum<64>(r_ * r_);
+    return r_;
+  };
+
+  double lam = dr * backward(y);                   // unscale: lam = D x
+  if (!is_pt) lam = 0.0;
+  double wv = at_times(lam);                       // lane p: bubble part of w_p (carried)
+  double nrm = 0.0;
+  double res = residual(lam, wv, nrm);
+#pragma unroll 1
+  for (int it = 0; it < nrefine; ++it) {           // safeguarded refinement, as in the generic kernel
+    double dl = dr * backward(forward(res));
+    if (!is_pt) dl = 0.0;
+    const double lam_c = lam + dl;
+    const double wv_c = wv + at_times(dl);
+    double nrm_c = 0.0;
+    const double res_c = residual(lam_c, wv_c, nrm_c);
+    const bool better = nrm_c < 4.0 * nrm;
+    const bool gains = better && (nrm_c < 0.25 * nrm);
+    lam = better ? lam_c : lam;
+    wv = better ? wv_c : wv;
+    res = better ? res_c : res;
+    nrm = better ? nrm_c : nrm;
+    if (!gains) break;                              // (nrm is wave-uniform: one element per wave)
+  }
+
+  // ---- w = w_bc + w', re-projected onto the boundary rows; store ------------------------------------
+  double wp = 0.0;
+  if (l < MP) wp = fma(LaS[l], g0, fma(LbS[l], g1, wv));
+  const double ra = group_sum<64>((l < MP) ? LaS[l] * wp : 0.0) - gl;
+  const double rb = group_sum<64>((l < MP) ? LbS[l] * wp : 0.0) - gr;
+  const double k0 = fma(qi00, ra, qi01 * rb), k1 = fma(qi01, ra, qi11 * rb);
+  if (l < MP) wp = fma(-k1, LbS[l], fma(-k0, LaS[l], wp));
+  const double bad = group_sum<64>((l < M && !(fabs(wp) < 1.0e300)) ? 1.0 : 0.0);
+  const bool ok = bad == 0.0;
+  double* const Wrow = p.W + e * (p.ldw ? p.ldw : (int64_t)M);
+  double out = wp;
+  if (!ok) out = (l == 0) ? 0.5 * (gl + gr) : (l == 1) ? 0.5 * (gr - gl) : 0.0;
+  if (l < M) Wrow[l] = out;
+  if (l == 0) {
+    if (p.status) p.status[e] = ok ? LSSVR_ST_OK : LSSVR_ST_FALLBACK;
+    if (!ok && p.fail_count) atomicAdd(p.fail_count, 1);
+  }
+}
+
+static hipError_t launch_dual_w64(const EnhanceArgs& a, hipStream_t s, const LaunchOpts* o) {
+  if (a.ne > 0x7fffffffLL) return hipErrorInvalidValue;
+  const dim3 grid((unsigned)a.ne), block(64);
+  const int nref = kRefine;
+  if (a.a_values) return launch(enhance_dual_w64_kernel<LSSVR_RHS_ARRAY, true>, grid, block, s, o, a, nref);
+  if (a.rhs_id == LSSVR_RHS_SIN) return launch(enhance_dual_w64_kernel<LSSVR_RHS_SIN, false>, grid, block, s, o, a, nref);
+  return launch(enhance_dual_w64_kernel<LSSVR_RHS_ARRAY, false>, grid, block, s, o, a, nref);
+}
+
 template <int LPE, int MP>
 static hipError_t launch_dual(const EnhanceArgs& a, hipStream_t s, const LaunchOpts* o) {
   constexpr int EPW = 64 / LPE;
@@ -434,7 +801,10 @@ hipError_t enhance_dual(const EnhanceArgs& a, hipStream_t s, const LaunchOpts* o
   const int need = a.n > a.M ? a.n : a.M;
   if (need <= 16) return launch_dual<16, 16>(a, s, o);
   if (need <= 32) return launch_dual<32, 32>(a, s, o);
-  return launch_dual<64, 36>(a, s, o);
+  // the register-lean wave-per-element kernel (round 3); LSSVR_DUAL_GENERIC64=1: the generic kernel (A/B)
+  static const bool generic64 = [] { const char* e = getenv("LSSVR_DUAL_GENERIC64"); return e && e[0] == '1'; }();
+  if (generic64) return launch_dual<64, 36>(a, s, o);
+  return launch_dual_w64(a, s, o);
 }
 
 }  // namespace lssvr
