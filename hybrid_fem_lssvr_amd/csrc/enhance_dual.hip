@@ -105,10 +105,13 @@ __device__ __forceinline__ double group_sum(double v) {
 
 }  // namespace
 
+#ifndef LSSVR_DUAL_MINW
+#define LSSVR_DUAL_MINW(LPE) ((LPE) == 16 ? 3 : (LPE) == 32 ? 2 : 1)
+#endif
 // LPE lanes per element, MP = padded number of Legendre coefficients (compile-time loop bound),
 // RHS as in the primal kernels, VC = variable-coefficient rows.
 template <int LPE, int MP, int RHS, bool VC>
-__global__ __launch_bounds__(64) void enhance_dual_kernel(EnhanceArgs p, int nrefine) {
+__global__ __launch_bounds__(64, LSSVR_DUAL_MINW(LPE)) void enhance_dual_kernel(EnhanceArgs p, int nrefine) {
   using L = DualLds<LPE, MP>;
   constexpr int EPW = 64 / LPE;
   __shared__ double2_t lds2[EPW * L::kSize / 2];
