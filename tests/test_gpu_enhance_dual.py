@@ -149,6 +149,47 @@ def test_dual_tabulated_rhs_and_variable_coefficients(dev):
             assert orc.rel_l2_coef(W.cpu().numpy()[sel], tr).max() <= 1e-12
 
 
+def test_dual_64_row_kernel_tabulated_and_variable_coefficients(dev):
+    """The wave-per-element kernel above 32 rows (enhance_dual_w64_kernel) in its tabulated and
+    variable-coefficient instantiations, both table layouts: RHS_ARRAY against the in-kernel sin, point-major
+    against element-major (bit-equal: the same values reach the same arithmetic), variable-coefficient rows
+    with n < M - 2 (the route lssvr_enhance_varcoef takes to this solver) against the 60-digit minimiser."""
+    import torch
+    from hybrid_fem_lssvr_amd import ops
+    for ne, M, n in ((150, 20, 50), (130, 33, 64), (70, 33, 40)):
+        nodes = np.linspace(-3, 5, ne + 1)
+        values = np.sin(np.pi * nodes)
+        x, u = _t(nodes, dev), _t(values, dev)
+        xc = ops.colloc_points(x, n)
+        f_em = _t(orc.poisson_rhs(xc.cpu().numpy()), dev)
+        f_pm = f_em.t().contiguous()
+        W0, _ = ops.enhance(x, u, M, 1e4, n, solver=ops.SOLVER_DUAL)
+        W1, s1 = ops.enhance(x, u, M, 1e4, n, rhs_values=f_em, solver=ops.SOLVER_DUAL)
+        W2, s2 = ops.enhance(x, u, M, 1e4, n, rhs_values=f_pm, point_major=True, solver=ops.SOLVER_DUAL)
+        torch.cuda.synchronize()
+        assert int(s1.sum()) == 0 and int(s2.sum()) == 0
+        assert torch.equal(W1, W2)
+        assert orc.rel_l2_coef(W1.cpu().numpy(), W0.cpu().numpy()).max() <= 1e-11
+    c, phi = orc.varcoef_params()
+    a, da, fv = orc.varcoef_functions(c, phi)
+    for ne, M, n in ((48, 33, 28), (40, 33, 20)):            # n < M-2 and M > 32: the 64-row kernel, VC rows
+        nodes = np.linspace(-1, 1, ne + 1)
+        values = orc.fem_p1_solve(nodes, rhs=fv, coef_a=a)
+        x = _t(nodes, dev)
+        xc = ops.colloc_points(x, n).cpu().numpy()
+        tabs = [_t(fn(xc), dev) for fn in (a, da, fv)]
+        W, st = ops.enhance_varcoef(x, _t(values, dev), M, 1e4, n, *tabs, global_domain=(-1.0, 1.0))
+        Wpm, stpm = ops.enhance_varcoef(x, _t(values, dev), M, 1e4, n, *[t.t().contiguous() for t in tabs],
+                                        global_domain=(-1.0, 1.0), point_major=True)
+        torch.cuda.synchronize()
+        assert int(st.sum()) == 0 and int(stpm.sum()) == 0
+        assert torch.equal(W, Wpm)
+        if cf.HAVE_MP:
+            sel = [0, ne // 3, ne - 1]
+            tr = cf.truth_all(nodes, values, M, 1e4, n, fv, (-1.0, 1.0), sel, coef_a=a, coef_da=da)
+            assert orc.rel_l2_coef(W.cpu().numpy()[sel], tr).max() <= 1e-12
+
+
 def test_dual_full_size_config4_sample(dev):
     """BASELINE config 4 (1e5 elements, degree 32, 64 points) through the dual solver: all finite,
     no fallback, boundary rows, sampled elements against the primal kernel and the oracle."""
