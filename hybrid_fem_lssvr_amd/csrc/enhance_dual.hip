@@ -457,6 +457,47 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
   const unsigned r2 = __builtin_amdgcn_readlane(v, 47), r3 = __builtin_amdgcn_readlane(v, 63);
   return max(max(r0, r1), max(r2, r3));
 }
+// The values of six doubles in lane P, as scalars.  v_readfirstlane_b32 under EXEC = {P} costs half the issue
+// time of v_readlane_b32 with an SGPR lane select (1.9 against 3.6 ns per wave instruction and SIMD,
+// scripts/micro/valu_rates.hip); EXEC is saved and restored inside the statement (nothing else is
+// clobbered: the mask is built by s_bfm_b64, which does not write SCC -- the compiler keeps loop
+// comparisons live in SCC across the statement), and the trailing s_nop covers the two wait states between a
+// VALU write of an SGPR and a VALU read of it.
+__device__ __forceinline__ void lane_values6(const double (&in)[6], double (&out)[6], int P) {
+  unsigned lo[6], hi[6], olo[6], ohi[6];
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, in[q]);
+    lo[q] = (unsigned)u;
+    hi[q] = (unsigned)(u >> 32);
+  }
+  unsigned long long sv;
+  asm volatile(
+      "s_mov_b64 %[sv], exec\n\t"
+      "s_bfm_b64 exec, 1, %[P]\n\t"            // one bit at position P; unlike s_lshl_b64 it leaves SCC alone
+      "v_readfirstlane_b32 %[a0], %[x0]\n\t"
+      "v_readfirstlane_b32 %[b0], %[y0]\n\t"
+      "v_readfirstlane_b32 %[a1], %[x1]\n\t"
+      "v_readfirstlane_b32 %[b1], %[y1]\n\t"
+      "v_readfirstlane_b32 %[a2], %[x2]\n\t"
+      "v_readfirstlane_b32 %[b2], %[y2]\n\t"
+      "v_readfirstlane_b32 %[a3], %[x3]\n\t"
+      "v_readfirstlane_b32 %[b3], %[y3]\n\t"
+      "v_readfirstlane_b32 %[a4], %[x4]\n\t"
+      "v_readfirstlane_b32 %[b4], %[y4]\n\t"
+      "v_readfirstlane_b32 %[a5], %[x5]\n\t"
+      "v_readfirstlane_b32 %[b5], %[y5]\n\t"
+      "s_mov_b64 exec, %[sv]\n\t"
+      "s_nop 1"
+      : [sv] "=&s"(sv), [a0] "=&s"(olo[0]), [b0] "=&s"(ohi[0]), [a1] "=&s"(olo[1]), [b1] "=&s"(ohi[1]),
+        [a2] "=&s"(olo[2]), [b2] "=&s"(ohi[2]), [a3] "=&s"(olo[3]), [b3] "=&s"(ohi[3]), [a4] "=&s"(olo[4]),
+        [b4] "=&s"(ohi[4]), [a5] "=&s"(olo[5]), [b5] "=&s"(ohi[5])
+      : [P] "s"(__builtin_amdgcn_readfirstlane(P)), [x0] "v"(lo[0]), [y0] "v"(hi[0]), [x1] "v"(lo[1]), [y1] "v"(hi[1]), [x2] "v"(lo[2]),
+        [y2] "v"(hi[2]), [x3] "v"(lo[3]), [y3] "v"(hi[3]), [x4] "v"(lo[4]), [y4] "v"(hi[4]), [x5] "v"(lo[5]),
+        [y5] "v"(hi[5]));
+#pragma unroll
+  for (int q = 0; q < 6; ++q) out[q] = __builtin_bit_cast(double, ((unsigned long long)ohi[q] << 32) | olo[q]);
+}
 constexpr int kW64MP = 36;             // padded number of Legendre coefficients in the row build (M <= 33)
 constexpr int kW64MU = kDualMaxM;      // columns of A' that can be non-zero
 constexpr int kW64ZS = 33;             // row stride of A' in LDS
@@ -648,16 +689,23 @@ __global__ __launch_bounds__(64, 2) void enhance_dual_w64_kernel(EnhanceArgs p, 
         const bool act = pivstep < 0;
         const double m = act ? krow[j] * rinv : 0.0;
         if (act) krow[j] = m;
-        // the pivot row, read out of lane P in batches of kB columns (independent SGPR pairs: the two wait
-        // states between a v_readlane and the FMA that takes its result are filled by the next reads)
+        // the pivot row, read out of lane P in batches of kB columns: v_readfirstlane under EXEC = {P}
+        // (lane_values6), v_readlane for the ragged last batch
         constexpr int kB = 6;
         const double nm = -m;
 #pragma unroll
         for (int c0 = j + 1; c0 < N; c0 += kB) {
           double u[kB];
+          if (c0 + kB <= N) {
+            double in[kB];
 #pragma unroll
-          for (int q = 0; q < kB; ++q)
-            if (c0 + q < N) u[q] = readlane_f64(krow[c0 + q], P);
+            for (int q = 0; q < kB; ++q) in[q] = krow[c0 + q];
+            lane_values6(in, u, P);
+          } else {
+#pragma unroll
+            for (int q = 0; q < kB; ++q)
+              if (c0 + q < N) u[q] = readlane_f64(krow[c0 + q], P);
+          }
 #pragma unroll
           for (int q = 0; q < kB; ++q)
             if (c0 + q < N) krow[c0 + q] = fma(nm, u[q], krow[c0 + q]);
@@ -674,7 +722,7 @@ __global__ __launch_bounds__(64, 2) void enhance_dual_w64_kernel(EnhanceArgs p, 
       constexpr int j = decltype(jc)::value;
       if (j < ns) {
         const int P = __builtin_amdgcn_readlane(pvec, j);
-        const double vj = readlane_f64(v, P);
+        const double vj = readlane_f64(v, P);      // (v_readfirstlane under EXEC = {P} is slower here: a serial chain)
         const double m = (pivstep > j) ? krow[j] : 0.0;   // (padding rows: krow[j] == 0 for j < n)
         v = fma(-m, vj, v);
       }

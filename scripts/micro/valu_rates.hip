@@ -38,6 +38,24 @@ __global__ __launch_bounds__(64) void rate_kernel(double* out, int iters, int la
                      : "=s"(s0), "=s"(s1), "=s"(s2), "=s"(s3) : "v"(((int*)&x)[0]), "s"(P));
       }
       asm volatile("" :: "s"(s0), "s"(s1), "s"(s2), "s"(s3));
+    } else if constexpr (KIND == 7) {       // v_readlane_b32, 16 distinct destination SGPRs per group
+      int s[16];
+#pragma unroll
+      for (int k = 0; k < kBody; k += 16) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) asm volatile("v_readlane_b32 %0, %1, %2" : "=s"(s[q]) : "v"(((int*)&acc[q & 7])[q & 1]), "s"(P));
+#pragma unroll
+        for (int q = 0; q < 16; ++q) asm volatile("" :: "s"(s[q]));
+      }
+    } else if constexpr (KIND == 8) {       // v_readfirstlane_b32
+      int s[16];
+#pragma unroll
+      for (int k = 0; k < kBody; k += 16) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(s[q]) : "v"(((int*)&acc[q & 7])[q & 1]));
+#pragma unroll
+        for (int q = 0; q < 16; ++q) asm volatile("" :: "s"(s[q]));
+      }
     } else if constexpr (KIND == 3) {       // the LU column update: 2 x v_readlane_b32 + v_fma_f64 (SGPR pair), batches of 6
 #pragma unroll
       for (int k = 0; k < kBody; k += 6) {
@@ -104,6 +122,8 @@ int main() {
   run<2, 40960>("v_readlane_b32 (SGPR lane select)", kBody, ghz);
   run<3, 20480>("column update: 2 v_readlane_b32 + v_fma_f64 (per instruction)", kBody * 3, ghz);
   run<3, 40960>("column update: 2 v_readlane_b32 + v_fma_f64 (per instruction)", kBody * 3, ghz);
+  run<7, 20480>("v_readlane_b32 (16 distinct destination SGPRs)", kBody, ghz);
+  run<8, 20480>("v_readfirstlane_b32 (16 distinct destination SGPRs)", kBody, ghz);
   run<4, 20480>("v_add_u32 (dependent chain)", kBody, ghz);
   run<5, 20480>("ds_read_b128 broadcast (uniform address), per read", kBody / 2, ghz);
   run<5, 40960>("ds_read_b128 broadcast (uniform address), per read", kBody / 2, ghz);
