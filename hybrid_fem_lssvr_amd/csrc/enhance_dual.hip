@@ -428,15 +428,16 @@ __global__ __launch_bounds__(64, LSSVR_DUAL_MINW(LPE)) void enhance_dual_kernel(
 // The generic kernel above at LPE = 64 holds a row of K (128 VGPRs) AND a row of A' (72) per lane, sends
 // the pivot row through LDS and searches the pivot with twelve 64-bit ds_bpermute: 256 VGPRs + 136 AGPRs,
 // one wave per SIMD, 23 400 instructions per element at the lone-wave issue rate (one instruction per
-// ~9 cycles): 12.4 ms per 1e5 elements.  Same algorithm here -- block-pivoted boundary rows, Jacobi
+// ~9 cycles): 12.4 ms per 1e5 elements (here: 17 500 at two waves per SIMD, 4.6 ms).  Same algorithm here -- block-pivoted boundary rows, Jacobi
 // equilibration, LU with PARTIAL PIVOTING, safeguarded refinement with the compensated operator residual --
 // arranged for the register file:
 //   * the rows of A' live in LDS (row stride 33, odd: conflict-free for a lane reading its own row and for
 //     a lane reading a column); the Gram takes four columns of A' at a time against 64 accumulators;
-//   * the pivot row never travels: every lane reads it out of lane P with v_readlane (SGPR operands of the
-//     FMA), no LDS round trip and no wave sync inside an elimination step (measured alternatives, DESIGN
-//     section 3.2b: the row through LDS with the publish overlapped by the next pivot search, 6.0 ms
-//     against 5.2 -- with 256 registers only three broadcast reads are in flight per wave);
+//   * the pivot row never travels: every lane reads it out of lane P into the SGPR operands of its FMAs
+//     (v_readfirstlane under EXEC = {P}, six columns per asm statement: 4.6 ms; with v_readlane, which
+//     costs twice the issue time, 5.2 ms), no LDS round trip and no wave sync inside an elimination step
+//     (measured alternative, DESIGN section 3.2b: the row through LDS with the publish overlapped by the
+//     next pivot search, three or sixteen broadcast reads in flight: 6.0 / 6.1 ms);
 //   * pivot search by a DPP max-reduction on 32-bit keys (exponent + 19 mantissa bits + lane);
 //   * <= 256 registers, so two waves share a SIMD and fill each other's issue gaps; 19 KB of LDS per wave,
 //     eight waves per CU.
