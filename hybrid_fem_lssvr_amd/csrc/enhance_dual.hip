@@ -463,7 +463,7 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
 // scripts/micro/valu_rates.hip); EXEC is saved and restored inside the statement (nothing else is
 // clobbered: the mask is built by s_bfm_b64, which does not write SCC -- the compiler keeps loop
 // comparisons live in SCC across the statement), and the trailing s_nop covers the two wait states between a
-// VALU write of an SGPR and a VALU read of it.
+// VALU write of an SGPR and a VALU read of it.  For wave-uniform control flow only (EXEC is replaced, not masked).
 __device__ __forceinline__ void lane_values6(const double (&in)[6], double (&out)[6], int P) {
   unsigned lo[6], hi[6], olo[6], ohi[6];
 #pragma unroll
