@@ -98,7 +98,7 @@ def test_dual_every_size_class_vs_primal(dev):
     from hybrid_fem_lssvr_amd import ops
     rng = np.random.default_rng(77)
     for M, n, ne in [(5, 5, 7), (9, 16, 1001), (12, 12, 33), (16, 16, 5), (17, 24, 203), (24, 32, 77),
-                     (9, 40, 130), (33, 64, 51), (20, 50, 9)]:
+                     (9, 40, 130), (33, 64, 51), (20, 50, 9), (2, 40, 9), (3, 64, 5)]:
         nodes = np.cumsum(np.concatenate([[-0.9], rng.uniform(0.01, 0.08, ne)]))
         values = np.sin(np.pi * nodes) + 0.01 * rng.standard_normal(ne + 1)
         gd = (nodes[0], nodes[-1])
@@ -112,6 +112,8 @@ def test_dual_every_size_class_vs_primal(dev):
         # kernel matrix has rank M-2 < n and eps = 1/(gamma scl^4) below its rounding noise u |K| leaves
         # the null-space part of lam to the noise of the factors; measured 1e-10 .. 5e-10 on single
         # elements once gamma scl^4 > 1e12 (here: M = n = 5, gamma 5e5, h 0.01: 3e14), <= 1e-11 below.
+        # (The envelope keeps growing with gamma scl^4 and with the rank deficit: M = 4 with 33 points at
+        # gamma scl^4 = 1.3e15 reads 8e-7 on single elements -- the regime the primal solver is for.)
         gt = gamma * (2.0 / np.diff(nodes).min()) ** 4
         tol = (1e-11 if M <= 22 else 1e-10) if (gt < 1e12 or n <= M - 2) else 2e-9
         assert orc.rel_l2_coef(Wd, Wo).max() <= tol, (M, n, gt)
