@@ -882,7 +882,11 @@ def run_config5(args, D, M, n, ne, lo, hi, dev, cpu_res):
         },
         "roofline": {
             "bound": "hbm",
-            "why": "arithmetic intensity %.1f flop/B is below the ridge (78.6 TFLOP/s / 8 TB/s = 9.8)" % (flops / byts),
+            "why": ("arithmetic intensity %.1f flop/B is below the ridge (78.6 TFLOP/s / 8 TB/s = 9.8), so HBM is the "
+                    "roofline that prices it; measured apart (profiles/r03_pm_pattern.txt): this table pattern alone "
+                    "streams at 5.9 TB/s (80 us for 472 B x 1e6), the kernel's 2 200 vector instructions per element "
+                    "take 77 us of issue time, and the two overlap only partly -- see roofline_fp64.executed"
+                    % (flops / byts)),
             "kernel": "enhance_small_kernel<M=%d, %s, varcoef>" % (M, "RHS_ARRAY_PM" if pm else "RHS_ARRAY"),
             "achieved": gbs,
             "peak": HBM_PEAK_GBS,
