@@ -32,7 +32,6 @@
 // Mapping: LPE = 16 / 32 / 64 lanes per element (the smallest that holds max(n, M)), 64 / LPE
 // elements per wave, one wave per workgroup, wave-private LDS.  Lane r of an element is collocation
 // row r: it keeps its row of A' (M values) and its row of K (n values) in registers.
-#include <cstdlib>
 #include "lssvr_device.hpp"
 #include "lssvr_kernels.hpp"
 #include "lssvr_wave.hpp"
@@ -853,9 +852,8 @@ hipError_t enhance_dual(const EnhanceArgs& a, hipStream_t s, const LaunchOpts* o
   const int need = a.n > a.M ? a.n : a.M;
   if (need <= 16) return launch_dual<16, 16>(a, s, o);
   if (need <= 32) return launch_dual<32, 32>(a, s, o);
-  // the register-lean wave-per-element kernel (round 3); LSSVR_DUAL_GENERIC64=1: the generic kernel (A/B)
-  static const bool generic64 = [] { const char* e = getenv("LSSVR_DUAL_GENERIC64"); return e && e[0] == '1'; }();
-  if (generic64) return launch_dual<64, 36>(a, s, o);
+  // above 32 rows: the register-lean wave-per-element kernel (round 3; the generic kernel at LPE = 64, 12.4 ms
+  // against 4.6 at BASELINE config 4, is no longer instantiated)
   return launch_dual_w64(a, s, o);
 }
 

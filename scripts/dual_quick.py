@@ -1,5 +1,4 @@
-"""Dual solver timing (hipExt-stamped launches) and agreement with the primal kernels.
-LSSVR_DUAL_GENERIC64=1: the generic wave-per-element kernel above 32 rows instead of the register-lean one."""
+"""Dual solver timing (hipExt-stamped launches) and agreement with the primal kernels."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
