@@ -1016,6 +1016,41 @@ def run_single(args, D, M, n, ne_glob, lo, hi, dev, cpu_res, use_dist):
         except Exception as exc:  # pragma: no cover
             pipelined = {"error": repr(exc)}
 
+    # the same K steps captured ONCE in a hipGraph and replayed (one stream, strictly sequential like
+    # `value`): what the launch path costs when the host is out of it.  Reported beside `value`.
+    graph_replay = None
+    if args.solver == "primal":
+        try:
+            wg = Workload(ne_glob, lo, hi, M, n, 0, 1, dev)
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                wg.plans[0].launch()                     # warm-up outside the capture
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                for _ in range(args.steps):
+                    wg.plans[0].launch()
+            graph.replay()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = []
+            for _ in range(5):
+                e0.record()
+                graph.replay()
+                e1.record()
+                torch.cuda.synchronize()
+                reps.append(e0.elapsed_time(e1))
+            reps.sort()
+            graph_replay = {"what": "the same K steps captured once in a hipGraph (one stream) and replayed; "
+                                    "median of 5 replays between HIP events",
+                            "value": ne_loc * args.steps / (reps[2] * 1e-3), "unit": "elements/s",
+                            "ms_per_step": reps[2] / args.steps,
+                            "results_equal": bool(torch.equal(wg.W[0], W))}
+            del graph, wg
+        except Exception as exc:  # pragma: no cover
+            graph_replay = {"error": repr(exc)}
+
     # the uniform-mesh shortcut (lssvr_enhance_shared; SURVEY.md 8(d): "reported as a separate line
     # if built"): one shared operator applied per element.  Never part of `value`; its own
     # roofline is HBM (88 B per element against ~8 TB/s).
@@ -1225,6 +1260,8 @@ def run_single(args, D, M, n, ne_glob, lo, hi, dev, cpu_res, use_dist):
         out["shared_operator"] = shared
     if pipelined is not None:
         out["pipelined"] = pipelined
+    if graph_replay is not None:
+        out["graph_replay"] = graph_replay
     out["accuracy"] = accuracy
     if cpu_res is not None:
         out["cpu_baseline"] = cpu_res
