@@ -31,3 +31,7 @@ g.replay(); torch.cuda.synchronize()
 tg = timed(g.replay)
 print(f"eager  : median {te[len(te)//2]:.2f} us per step, min {te[0]:.2f}")
 print(f"graph  : median {tg[len(tg)//2]:.2f} us per step, min {tg[0]:.2f}")
+import time
+torch.cuda.synchronize()
+t0 = time.perf_counter(); eager(); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+print(f"host   : issuing {K} eager launches took {(t1-t0)/K*1e6:.2f} us per launch; drained {(t2-t1)*1e6:.0f} us later")
