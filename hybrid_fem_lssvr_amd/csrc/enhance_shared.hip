@@ -178,6 +178,15 @@ __global__ __launch_bounds__(kBlock) void enhance_shared_kernel(EnhanceArgs p,
   __builtin_amdgcn_wave_barrier();
   const int64_t base = ((int64_t)blockIdx.x * kBlock + (tid & ~63)) * M;
   const int64_t total = p.ne * M;
+  if (total <= kWriteThroughMaxDoubles) {
+    // small outputs: write-through stores (see kWriteThroughMaxDoubles)
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+      const int64_t idx = base + (int64_t)i * 64 + lane;
+      if (idx < total) __hip_atomic_store(&p.W[idx], wt[i * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < M; ++i) {
     const int64_t idx = base + (int64_t)i * 64 + lane;

@@ -9,6 +9,12 @@
 namespace lssvr {
 
 constexpr int kSmallMaxM = 22;   // lane-per-element path: (M-2)(M-1)/2 Gram entries in VGPRs + AGPRs
+// Coefficient tiles up to this many doubles (16 MiB) are stored WRITE-THROUGH (system-scope stores: sc0 sc1):
+// an eagerly launched kernel ends with a write-back of its dirty lines before the next dispatch may start, and
+// at BASELINE's 1e5 elements (7.2 MB of W) that tail was 0.6 of the kernel's 9.7 us; written through, the lines
+// drain while other waves still compute.  Larger outputs keep non-temporal stores (measured: equal from 3e5 to
+// 3e6 elements, write-through 2-4 % slower at 1e7).
+constexpr int64_t kWriteThroughMaxDoubles = int64_t(1) << 21;
 constexpr int kLargeMaxM = 33;   // wave-per-element MFMA path: M-2 bubble coefficients + rhs <= 32
 
 struct EnhanceArgs {
