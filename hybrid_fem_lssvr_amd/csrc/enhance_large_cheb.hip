@@ -457,7 +457,12 @@ __global__ __launch_bounds__(kMomBlock, 2) void moments_kernel(EnhanceArgs p, do
 #pragma unroll
     for (int i = 0; i < 32; ++i) {
       const int row = 2 * i + (lane >> 5), cc = lane & 31;
-      if (e0 + row < p.ne) ws[(e0 + row) * kWsStride + c0 + cc] = tl[row * 33 + cc];
+      // write-through (system-scope) stores: the rows drain while other waves still accumulate instead of
+      // waiting in the caches for the end-of-kernel release that precedes the solve kernel (-3 us of the pair
+      // at 1e5 elements, -0.5 % at 1e6: alternating A/B)
+      if (e0 + row < p.ne)
+        __hip_atomic_store(&ws[(e0 + row) * kWsStride + c0 + cc], tl[row * 33 + cc], __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
     }
   });
 }
