@@ -1220,6 +1220,12 @@ def run_single(args, D, M, n, ne_glob, lo, hi, dev, cpu_res, use_dist):
             "elements_per_launch": ne_loc,
             "kernel_us_avg": k_dur * 1e6,
             "kernel_us_median": k_med * 1e6,
+            "kernel_us_is": "begin -> end stamps of the dispatch (hipExtLaunchKernelGGL events = rocprofv3's kernel "
+                            "duration).  They include ~4.1 us of dispatch that an EMPTY kernel also reads and of which "
+                            "~1 us overlaps the previous launch in a back-to-back sequence (empty kernel: 4.1 us stamped, "
+                            "3.1 us per launch back to back; profiles/r03_launch_floor.txt) -- so ms_per_step of K "
+                            "back-to-back steps can be SMALLER than this duration at 1e5 elements; it is not a "
+                            "different amount of work",
             "traffic": None,
             "traffic_source": None,
         },

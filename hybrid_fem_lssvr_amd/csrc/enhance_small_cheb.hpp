@@ -536,7 +536,11 @@ __device__ __forceinline__ void enhance_small_body_cheb(const EnhanceArgs& p, co
       return;
     }
 #endif
-    if (live && p.status) p.status[id] = st;
+    if (live && p.status) {
+      if (p.ne * (int64_t)M <= kWriteThroughMaxDoubles)          // small launch: write-through, like W below
+        __hip_atomic_store(&p.status[id], st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      else p.status[id] = st;
+    }
     if (live && scattered) {
       // heterogeneous launch: rows go to the mesh index, ldw apart (direct stores)
       double* const Wrow = p.W + id * (p.ldw ? p.ldw : (int64_t)M);

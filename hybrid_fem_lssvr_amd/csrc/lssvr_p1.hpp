@@ -71,6 +71,14 @@ __device__ __forceinline__ ElemLocal p1_element(const P1Args& p, const QuadRule&
   return r;
 }
 
+// The three bands of a small mesh (<= kWriteThroughMaxDoubles nodes) are stored write-through, like the lane
+// kernels' coefficient tiles: in the fused step the assembly blocks are the grid's tail, so their dirty lines
+// would all wait for the end-of-kernel release.
+__device__ __forceinline__ void band_store(const P1Args& p, double* dst, double v) {
+  if (p.ne <= kWriteThroughMaxDoubles) __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  else *dst = v;
+}
+
 // One thread per NODE i (see above): both adjacent elements, race-free gather.
 template <bool SIN>
 __device__ __forceinline__ void p1_node(const P1Args& p, const QuadRule& q, int64_t i) {
@@ -79,7 +87,7 @@ __device__ __forceinline__ void p1_node(const P1Args& p, const QuadRule& q, int6
     const ElemLocal r = p1_element<SIN>(p, q, i);
     d += r.k;
     l += r.fl;
-    p.off[i] = -r.k;
+    band_store(p, &p.off[i], -r.k);
     if (p.kloc) p.kloc[i] = r.k;
     if (p.floc) {
       p.floc[2 * i] = r.fl;
@@ -91,8 +99,8 @@ __device__ __forceinline__ void p1_node(const P1Args& p, const QuadRule& q, int6
     d += r.k;
     l += r.fr;
   }
-  p.diag[i] = d;
-  p.load[i] = l;
+  band_store(p, &p.diag[i], d);
+  band_store(p, &p.load[i], l);
 }
 
 }  // namespace lssvr
