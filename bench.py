@@ -1022,15 +1022,7 @@ def run_single(args, D, M, n, ne_glob, lo, hi, dev, cpu_res, use_dist):
     if args.solver == "primal":
         try:
             wg = Workload(ne_glob, lo, hi, M, n, 0, 1, dev)
-            side = torch.cuda.Stream(device=dev)
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                wg.plans[0].launch()                     # warm-up outside the capture
-            torch.cuda.current_stream().wait_stream(side)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                for _ in range(args.steps):
-                    wg.plans[0].launch()
+            graph = ops.StepGraph(wg.plans[0], steps=args.steps)
             graph.replay()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

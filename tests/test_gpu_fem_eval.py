@@ -385,6 +385,30 @@ def test_step_is_hip_graph_capturable(dev):
     assert torch.equal(W_g, W_e) and torch.equal(uq_graph, uq_e)
 
 
+def test_step_graph_replays_equal_eager_steps(dev):
+    """ops.StepGraph: K launches of a bound plan captured once; a replay after new nodal values were
+    written in place gives what an eager launch gives."""
+    import torch
+    from hybrid_fem_lssvr_amd import ops
+    ne, M, n = 5000, 9, 16
+    nodes = np.linspace(-2, 2, ne + 1)
+    x = _t(nodes, dev)
+    u = _t(np.sin(np.pi * nodes), dev)
+    plan = ops.StepPlan(x, u, M, 1e4, n, global_domain=(-2.0, 2.0))
+    g = ops.StepGraph(plan, steps=3)
+    u.copy_(_t(np.cos(0.5 * nodes), dev))
+    W, st = g.replay()
+    torch.cuda.synchronize()
+    W_g = W.clone()
+    assert int(st.sum()) == 0
+    W_e, _ = ops.enhance(x, u, M, 1e4, n, global_domain=(-2.0, 2.0))
+    assert torch.equal(W_g, W_e)
+    bands = {k: v.clone() for k, v in plan.bands.items()}
+    plan.launch()
+    torch.cuda.synchronize()
+    assert all(torch.equal(bands[k], plan.bands[k]) for k in bands)
+
+
 def test_c_abi_demo_program(dev):
     """examples/c_abi_demo.cpp drives the whole solve-then-enhance path through the C ABI alone
     (hipMalloc'd buffers, no Python, no torch) and checks the reference demo's error figures."""
