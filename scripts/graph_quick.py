@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from hybrid_fem_lssvr_amd import ops
 dev = "cuda:0"
-ne, M, n, K = 100008, 9, 16, 200
+ne, M, n, K = (int(sys.argv[1]) if len(sys.argv) > 1 else 100008), 9, 16, (int(sys.argv[2]) if len(sys.argv) > 2 else 200)
 half = ne / 24.0
 nodes = np.arange(ne + 1, dtype=np.float64) * (2 * half / ne) - half
 x = torch.as_tensor(nodes, device=dev); u = torch.sin(np.pi * x)
