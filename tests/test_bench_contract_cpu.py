@@ -34,8 +34,11 @@ def test_default_bench_line_contract(name):
     # achieved = algorithmic flops per launch / the kernel's average launch duration
     flops = r["flops_per_element"] * r["elements_per_launch"]
     assert abs(r["achieved"] - flops / (r["kernel_us_avg"] * 1e-6) / 1e12) <= 1e-9 * r["achieved"]
-    # the dominant kernel fits inside the step it dominates
-    assert r["kernel_us_avg"] * 1e-3 <= 1.05 * j["ms_per_step"]
+    # the dominant kernel fits inside the step it dominates -- up to the part of a dispatch's begin -> end
+    # stamps that overlaps the previous launch in a back-to-back sequence: an EMPTY kernel reads 4.1 us
+    # stamped and 3.1 us per launch back to back (profiles/r03_launch_floor.txt), so K back-to-back steps of a
+    # ~5 us kernel take up to ~1 us per step LESS than K stamped durations (roofline.kernel_us_is says so)
+    assert r["kernel_us_avg"] * 1e-3 <= max(1.05 * j["ms_per_step"], j["ms_per_step"] + 1.2e-3)
     c = j["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
