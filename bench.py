@@ -55,8 +55,14 @@ NE_CONFIG3 = 10000008                      # BASELINE config 3, h = 1/12 on [-41
 FP64_PEAK_TFLOPS = 78.6                    # MI355X vector = matrix FP64 peak (SURVEY.md 8(d):
                                            # 256 CU x 4 SIMD x 32 FLOP/clk x 2.4 GHz); probe below
 HBM_PEAK_GBS = 8000.0
-PREWARM_SECONDS = float(os.environ.get("LSSVR_BENCH_PREWARM", "0.03"))
+PREWARM_SECONDS = float(os.environ.get("LSSVR_BENCH_PREWARM", "0.05"))
 PREWARM_DONE = 0
+# The timed region: the K steps are captured ONCE in a hipGraph (untimed, like the warm-up) and the replay is
+# timed -- the loop is launch-bound at BASELINE's size (the host needs ~7 us per call by call launch, the step
+# takes ~8), which is the case hipGraphs are for.  LSSVR_BENCH_TIMED=eager: K launches issued call by call.
+# The other mode is measured as well and reported beside `value` (`eager_loop` / `graph_replay`).
+TIMED_MODE = os.environ.get("LSSVR_BENCH_TIMED", "graph")
+TIMED_USED = []            # mode each timed_compute call really used ("graph" / "eager (<why>)"), in call order
 SAMPLES_PER_ELEMENT = 2                    # u is stitched on the uniform grid of spacing h/2 (--stitch-samples)
 NE_C5_WIDE = 1000008                       # BASELINE config 5 on [-41667, 41667], h = 1/12 exactly
 NE_C5_NARROW = 1000000                     # ... and on [-1, 1] as BASELINE words it
@@ -292,42 +298,66 @@ class Dist:
         return self.max(0.0 if ok else 1.0) == 0.0
 
 
-def timed_compute(wl, D, steps, warmup):
-    """K launches of the fused step on the current stream between two HIP events; barrier +
-    device synchronisation on both sides, nothing but launches inside.  Returns (max over ranks
-    of the device time [s], max over ranks of the host wall time [s])."""
+def prewarm(launch, st):
+    """Steady state before the W warm-up steps: the chip idles while the CPU baseline runs, and W steps of a few
+    microseconds do not bring it back (measured: 0.61 against 0.51 ms per step at 1e7 elements, 8.6 against 8.0 us
+    at 1e5) -- at least PREWARM_SECONDS of the same launches, untimed.  LSSVR_BENCH_PREWARM=0 switches it off; the
+    count of the first (headline) measurement is reported as `prewarm_steps`."""
     import torch
+    global PREWARM_DONE
+    if PREWARM_SECONDS <= 0:
+        return 0
+    launch(st)                                     # (first call: lazy initialisation, not an estimate)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(8):
+        launch(st)
+    torch.cuda.synchronize()
+    est = max((time.perf_counter() - t0) / 8, 1e-6)
+    pre = int(min(40000, max(0, PREWARM_SECONDS / est)))
+    for _ in range(pre):
+        launch(st)
+    torch.cuda.synchronize()
+    if PREWARM_DONE == 0:
+        PREWARM_DONE = pre + 9
+    return pre + 9
+
+
+def timed_compute(wl, D, steps, warmup, mode=None):
+    """K steps of the fused step on the current stream between two HIP events; barrier + device
+    synchronisation on both sides, nothing but the launches (mode "eager") or the replay of the K captured
+    launches (mode "graph", see TIMED_MODE) inside.  Returns (max over ranks of the device time [s], max over
+    ranks of the host wall time [s]); the mode really used is appended to TIMED_USED."""
+    import torch
+    from hybrid_fem_lssvr_amd import ops
     st = torch.cuda.current_stream().cuda_stream
     plan = wl.plans[0]
-    # clock ramp: the chip idles while the CPU baseline runs, and W steps of a few microseconds do not bring
-    # the clocks back -- at least PREWARM_SECONDS of the same launches, untimed, come before the W warm-up steps
-    # (LSSVR_BENCH_PREWARM=0 switches it off; the count is reported as `prewarm_steps`)
-    global PREWARM_DONE
-    pre = 0
-    if PREWARM_SECONDS > 0:
-        plan.launch(st)                            # (first call: lazy initialisation, not an estimate)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(8):
-            plan.launch(st)
-        torch.cuda.synchronize()
-        est = max((time.perf_counter() - t0) / 8, 1e-6)
-        pre = int(min(4000, max(0, PREWARM_SECONDS / est)))
-        for _ in range(pre):
-            plan.launch(st)
-        torch.cuda.synchronize()
-        if PREWARM_DONE == 0:                      # (reported for the first, i.e. the headline, measurement)
-            PREWARM_DONE = pre + 9
+    mode = mode or TIMED_MODE
+    prewarm(plan.launch, st)
     for _ in range(warmup):
         plan.launch(st)
+    graph, used = None, "eager"
+    if mode == "graph":
+        try:
+            torch.cuda.synchronize()
+            graph = ops.StepGraph(plan, steps=steps)
+            graph.replay()                             # (untimed: the first replay uploads the graph)
+            torch.cuda.synchronize()
+            used = "graph"
+        except Exception as exc:  # pragma: no cover
+            graph, used = None, "eager (hipGraph capture failed: %r)" % (exc,)
+    TIMED_USED.append(used)
     D.barrier()
     D.barrier()
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()
-    for _ in range(steps):
-        plan.launch(st)
+    if graph is not None:
+        graph.replay()
+    else:
+        for _ in range(steps):
+            plan.launch(st)
     e1.record()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
@@ -420,7 +450,9 @@ def measure_multi(wl, D, steps, warmup, algos, samples_list=(2, 1)):
     total = wl.ne_glob * steps
     res = {"elements_total": wl.ne_glob, "elements_per_rank": wl.plan.max_size,
            "value": total / dev_s, "ms_per_step": dev_s / steps * 1e3,
-           "host_wall_ms_per_step": wall_s / steps * 1e3}
+           "host_wall_ms_per_step": wall_s / steps * 1e3,
+           "timed_region": ("the K steps captured once in a hipGraph per rank (untimed, like the warm-up) and replayed"
+                            if TIMED_USED[-1].startswith("graph") else "K launches issued call by call: " + TIMED_USED[-1])}
     jobs = [("u", sp) for sp in samples_list] + [("W", None)]
     for what, sp in jobs:
         by_algo = {}
@@ -685,7 +717,8 @@ def run_multi(args, D, M, n, ne_glob, lo, hi, rank, world, dev, backend):
                            "no data-path collective before or during the kernels" % world,
             "solver": "primal, BC-eliminated SPD (M-2), Chebyshev-moment Gram, LDL^T",
             "fallback_elements": int(n_fallback),
-            "timing": "per-rank HIP events around the K launches (after barrier + device sync), max over ranks taken after the region",
+            "timing": "per-rank HIP events around the K steps (after barrier + device sync), max over ranks taken after the region",
+            "timed_region": res.get("timed_region"),
         },
         "stitch_u": res.get("stitch_u"),
         "stitch_W": res.get("stitch_W"),
@@ -771,33 +804,30 @@ def run_config5(args, D, M, n, ne, lo, hi, dev, cpu_res):
         return ops.enhance_varcoef(w["x"], w["u"], M, GAMMA, n, w["a"], w["da"], w["f"], global_domain=w["gd"],
                                    out=w["W"], status=w["st"], point_major=w["pm"], **kw)
 
-    def step_fn(w):
-        plan = ops.StepPlanVarcoef(w["x"], w["u"], M, GAMMA, n, w["a"], w["da"], w["f"], w["fq"], w["aq"],
+    def step_plan(w):
+        return ops.StepPlanVarcoef(w["x"], w["u"], M, GAMMA, n, w["a"], w["da"], w["f"], w["fq"], w["aq"],
                                    nquad=2, point_major=w["pm"], global_domain=w["gd"], bands=w["bands"],
                                    out=w["W"], status=w["st"])
-        return plan.launch
 
-    def timed(w, steps, warmup):
-        go = step_fn(w)
-        st = torch.cuda.current_stream().cuda_stream
-        for _ in range(warmup):
-            go(st)
-        D.barrier()
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        e0.record()
-        for _ in range(steps):
-            go(st)
-        e1.record()
-        torch.cuda.synchronize()
-        wall = time.perf_counter() - t0
-        return e0.elapsed_time(e1) * 1e-3, wall
+    def timed(w, steps, warmup, mode=None):
+        class _One:                                  # (timed_compute's view of a workload: .plans[0])
+            plans = [step_plan(w)]
+        return timed_compute(_One, D, steps, warmup, mode=mode)
 
     steps, warmup = args.steps, args.warmup
     pm = args.table_layout == "point"
     w = build(ne, lo, hi, pm)
     dev_s, wall_s = timed(w, steps, warmup)
+    timed_used = TIMED_USED[-1]
+    eager_loop = None
+    if timed_used.startswith("graph"):
+        try:
+            de, we = timed(w, steps, warmup, mode="eager")
+            eager_loop = {"what": "the same K steps issued call by call from Python (one stream)",
+                          "value": ne * steps / de, "unit": "elements/s", "ms_per_step": de / steps * 1e3,
+                          "host_wall_ms_per_step": we / steps * 1e3}
+        except Exception as exc:  # pragma: no cover
+            eager_loop = {"error": repr(exc)}
     n_fallback = int(w["st"].sum().item())
     k_s = sorted(enh(w, profiled=True) for _ in range(min(steps, 50)))
     k_avg, k_med = sum(k_s) / len(k_s), k_s[len(k_s) // 2]
@@ -880,6 +910,7 @@ def run_config5(args, D, M, n, ne, lo, hi, dev, cpu_res):
         "n_gpus": 1,
         "steps": steps,
         "warmup": warmup,
+        "prewarm_steps": PREWARM_DONE,
         "ms_per_step": dev_s / steps * 1e3,
         "host_wall_ms_per_step": wall_s / steps * 1e3,
         "higher_is_better": True,
@@ -901,6 +932,8 @@ def run_config5(args, D, M, n, ne, lo, hi, dev, cpu_res):
             "solver": "primal, BC-eliminated SPD (M-2), direct Gram of the weighted rows, LDL^T (lane per element)",
             "fallback_elements": n_fallback,
             "timing": "HIP events around the K steps on the launch stream, device synchronised on both sides",
+            "timed_region": ("the K steps captured once in a hipGraph (untimed, like the warm-up) and replayed"
+                             if timed_used.startswith("graph") else "K launches issued call by call: " + timed_used),
         },
         "roofline": {
             "bound": "hbm",
@@ -948,6 +981,8 @@ def run_config5(args, D, M, n, ne, lo, hi, dev, cpu_res):
                                                      % tj.get("_round", "committed profile"))
         except Exception:
             pass
+    if eager_loop is not None:
+        out["eager_loop"] = eager_loop
     if other is not None:
         out["other_table_layout"] = other
     if narrow is not None:
@@ -973,11 +1008,13 @@ def run_single(args, D, M, n, ne_glob, lo, hi, dev, cpu_res, use_dist):
     if args.solver == "dual":
         # the dual Gram solver has no fused step: a step is assembly + enhancement, two launches
         class _TwoLaunch:
-            def launch(self, s):
+            def launch(self, s=None):
                 ops.p1_assemble(x, 2, out=wl.bands, stream=s)
                 ops.enhance(x, u, M, GAMMA, n, global_domain=gd, solver=solver_id, out=W, status=status, stream=s)
+        _TwoLaunch.W, _TwoLaunch.status = W, status
         wl.plans = [_TwoLaunch()]
     dev_s, wall_s = timed_compute(wl, D, args.steps, args.warmup)
+    timed_used = TIMED_USED[-1]
     elapsed = dev_s
     n_fallback = int(status.sum().item())
 
@@ -1038,32 +1075,23 @@ def run_single(args, D, M, n, ne_glob, lo, hi, dev, cpu_res, use_dist):
         except Exception as exc:  # pragma: no cover
             pipelined = {"error": repr(exc)}
 
-    # the same K steps captured ONCE in a hipGraph and replayed (one stream, strictly sequential like
-    # `value`): what the launch path costs when the host is out of it.  Reported beside `value`.
-    graph_replay = None
-    if args.solver == "primal":
+    # the OTHER way of issuing the same K steps (see TIMED_MODE), same plan, same buffers: reported beside `value`
+    other_mode = None
+    if True:
         try:
-            wg = Workload(ne_glob, lo, hi, M, n, 0, 1, dev)
-            graph = ops.StepGraph(wg.plans[0], steps=args.steps)
-            graph.replay()
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            reps = []
-            for _ in range(5):
-                e0.record()
-                graph.replay()
-                e1.record()
-                torch.cuda.synchronize()
-                reps.append(e0.elapsed_time(e1))
-            reps.sort()
-            graph_replay = {"what": "the same K steps captured once in a hipGraph (one stream) and replayed; "
-                                    "median of 5 replays between HIP events",
-                            "value": ne_loc * args.steps / (reps[2] * 1e-3), "unit": "elements/s",
-                            "ms_per_step": reps[2] / args.steps,
-                            "results_equal": bool(torch.equal(wg.W[0], W))}
-            del graph, wg
+            alt = "eager" if timed_used.startswith("graph") else "graph"
+            W_ref = W.clone()
+            da, wa = timed_compute(wl, D, args.steps, args.warmup, mode=alt)
+            other_mode = {"what": ("the same K steps issued call by call from Python (one stream)" if alt == "eager"
+                                   else "the same K steps captured once in a hipGraph (one stream) and replayed"),
+                          "mode_used": TIMED_USED[-1],
+                          "value": ne_loc * args.steps / da, "unit": "elements/s",
+                          "ms_per_step": da / args.steps * 1e3, "host_wall_ms_per_step": wa / args.steps * 1e3,
+                          "results_equal": bool(torch.equal(W_ref, W))}
+            del W_ref
+            other_key = "eager_loop" if alt == "eager" else "graph_replay"
         except Exception as exc:  # pragma: no cover
-            graph_replay = {"error": repr(exc)}
+            other_mode, other_key = {"error": repr(exc)}, "other_timed_mode"
 
     # the uniform-mesh shortcut (lssvr_enhance_shared; SURVEY.md 8(d): "reported as a separate line
     # if built"): one shared operator applied per element.  Never part of `value`; its own
@@ -1214,7 +1242,9 @@ def run_single(args, D, M, n, ne_glob, lo, hi, dev, cpu_res, use_dist):
             "parallelism": "one rank",
             "solver": solver_lbl,
             "fallback_elements": n_fallback,
-            "timing": "HIP events around the K launches on the launch stream, device synchronised on both sides",
+            "timing": "HIP events around the K steps on the launch stream, device synchronised on both sides",
+            "timed_region": ("the K steps captured once in a hipGraph (untimed, like the warm-up) and replayed" if timed_used.startswith("graph")
+                             else "K launches issued call by call: " + timed_used),
         },
         "roofline": {
             "bound": bound,
@@ -1281,8 +1311,8 @@ def run_single(args, D, M, n, ne_glob, lo, hi, dev, cpu_res, use_dist):
         out["shared_operator"] = shared
     if pipelined is not None:
         out["pipelined"] = pipelined
-    if graph_replay is not None:
-        out["graph_replay"] = graph_replay
+    if other_mode is not None:
+        out[other_key] = other_mode
     out["accuracy"] = accuracy
     if cpu_res is not None:
         out["cpu_baseline"] = cpu_res
