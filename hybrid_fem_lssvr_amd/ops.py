@@ -445,7 +445,9 @@ class StepGraph:
             plan.launch()                               # warm-up outside the capture
         torch.cuda.current_stream(plan.W.device).wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread_local: other threads of the process (torch.distributed's watchdog polls events) may keep
+        # calling the runtime while this thread captures
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             for _ in range(self.steps):
                 plan.launch()
 
