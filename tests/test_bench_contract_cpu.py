@@ -39,6 +39,14 @@ def test_default_bench_line_contract(name):
     # stamped and 3.1 us per launch back to back (profiles/r03_launch_floor.txt), so K back-to-back steps of a
     # ~5 us kernel take up to ~1 us per step LESS than K stamped durations (roofline.kernel_us_is says so)
     assert r["kernel_us_avg"] * 1e-3 <= max(1.05 * j["ms_per_step"], j["ms_per_step"] + 1.2e-3)
+    # how the K steps were timed is part of the line: warm steady state first, the replay of the captured steps
+    # timed, the loop issued call by call measured beside it on the same buffers
+    if name.startswith("r03"):                  # (fields of the round-3 line)
+        assert j["prewarm_steps"] >= 9
+        assert j["config"]["timed_region"].startswith("the K steps captured once in a hipGraph")
+        e = j["eager_loop"]
+        assert e["results_equal"] is True and e["mode_used"] == "eager"
+        assert 0.7 * j["ms_per_step"] <= e["ms_per_step"] <= 1.5 * j["ms_per_step"]
     c = j["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
