@@ -1031,11 +1031,19 @@ def run_single(args, D, M, n, ne_glob, lo, hi, dev, cpu_res, use_dist):
     # hipExtLaunchKernelGGL stamps with the dispatch's own begin / end times -- the quantity
     # rocprofv3 --kernel-trace reports -- over the same launch as in the timed region,
     # right after it (a plain hipEventRecord pair adds ~4 us of dispatch latency)
+    # ... INSIDE a running sequence of the same launches (lssvr_enhance_ws_sequence: every launch stamped, one
+    # synchronisation at the end), as in the timed region; the same launch in isolation (an idle chip before and
+    # after every one) is reported beside it
+    nprof = min(args.steps, 100)
+    ops.enhance_profiled(x, u, M, GAMMA, n, global_domain=gd, out=W, status=status, solver=solver_id,
+                         repeats=max(nprof, 20))                                  # (untimed: steady state)
     k_s = sorted(ops.enhance_profiled(x, u, M, GAMMA, n, global_domain=gd, out=W, status=status,
-                                      solver=solver_id)
-                 for _ in range(min(args.steps, 100)))
+                                      solver=solver_id, repeats=nprof))
     k_avg = sum(k_s) / len(k_s)
     k_med = k_s[len(k_s) // 2]
+    k_iso = sorted(ops.enhance_profiled(x, u, M, GAMMA, n, global_domain=gd, out=W, status=status,
+                                        solver=solver_id)
+                   for _ in range(min(args.steps, 30)))
 
     default_run = (args.domain == "wide" and not args.elements and args.solver == "primal")
     # the same step on exactly 1e5 elements of [-1, 1] (BASELINE.json's wording of config 2),
@@ -1265,7 +1273,11 @@ def run_single(args, D, M, n, ne_glob, lo, hi, dev, cpu_res, use_dist):
             "elements_per_launch": ne_loc,
             "kernel_us_avg": k_dur * 1e6,
             "kernel_us_median": k_med * 1e6,
-            "kernel_us_is": "begin -> end stamps of the dispatch (hipExtLaunchKernelGGL events = rocprofv3's kernel "
+            "kernel_us_isolated_avg": sum(k_iso) / len(k_iso) * 1e6,
+            "kernel_us_is": "average over %d launches of the enhancement issued back to back, each with its own "
+                            "begin -> end stamps, one synchronisation at the end (kernel_us_isolated_avg: the same "
+                            "launch with a synchronisation around every one).  " % nprof +
+                            "begin -> end stamps of the dispatch (hipExtLaunchKernelGGL events = rocprofv3's kernel "
                             "duration).  They include ~4.1 us of dispatch that an EMPTY kernel also reads and of which "
                             "~1 us overlaps the previous launch in a back-to-back sequence (empty kernel: 4.1 us stamped, "
                             "3.1 us per launch back to back; profiles/r03_launch_floor.txt) -- so ms_per_step of K "

@@ -50,6 +50,12 @@ SIGNATURES = {
                                   _c_int, _c_int, _c_dbl,
                                   _c_int, C.POINTER(_c_dbl), _c_dp, _c_int,
                                   _c_dp, _c_dp, _c_dp, _c_dp, _c_i64, _c_dp, C.POINTER(C.c_float)]),
+    "lssvr_enhance_ws_sequence": (_c_int, [_c_dp, _c_dp, _c_i64, _c_i64, _c_i64,
+                                           _c_dbl, _c_dbl, _c_dbl, _c_dbl,
+                                           _c_int, _c_int, _c_dbl,
+                                           _c_int, C.POINTER(_c_dbl), _c_dp, _c_int,
+                                           _c_dp, _c_dp, _c_dp, _c_dp, _c_i64, _c_dp,
+                                           _c_int, C.POINTER(C.c_float)]),
     "lssvr_enhance_profiled": (_c_int, [_c_dp, _c_dp, _c_i64, _c_i64, _c_i64,
                                         _c_dbl, _c_dbl, _c_dbl, _c_dbl,
                                         _c_int, _c_int, _c_dbl,

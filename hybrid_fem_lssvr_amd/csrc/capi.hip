@@ -1,6 +1,7 @@
 // extern "C" layer: argument validation, error strings, dispatch.  No torch,
 // no Python types -- plain pointers and sizes (include/lssvr_hip.h).
 #include <cstdarg>
+#include <vector>
 #include <cstdio>
 #include <cstring>
 
@@ -203,6 +204,51 @@ int lssvr_enhance_ws(const double* x, const double* u, int64_t ne, int64_t elem_
                 n_colloc, solver_id, (long long)need);
   if (ne == 0) return LSSVR_OK;
   return dispatch_timed(a, solver_id, reinterpret_cast<hipStream_t>(stream), work, work_bytes, kernel_ms_host);
+}
+
+int lssvr_enhance_ws_sequence(const double* x, const double* u, int64_t ne, int64_t elem_offset,
+                              int64_t ne_global, double gxmin, double gxmax, double bc_left, double bc_right,
+                              int M, int n_colloc, double gamma, int rhs_id, const double* rhs_params_host,
+                              const double* rhs_values, int solver_id, double* W, int32_t* status,
+                              int32_t* fail_count, void* work, int64_t work_bytes, void* stream,
+                              int repeats, float* kernel_ms_host) {
+  if (!kernel_ms_host) return fail(LSSVR_ERR_NULL, "kernel_ms_host must be non-NULL (float[repeats])");
+  if (repeats < 1 || repeats > 100000) return fail(LSSVR_ERR_SIZE, "repeats = %d outside [1, 100000]", repeats);
+  if (ne < 1) return fail(LSSVR_ERR_SIZE, "nothing to profile: ne = %lld", (long long)ne);
+  lssvr::EnhanceArgs a;
+  int rc = fill_enhance_args(a, x, u, ne, elem_offset, ne_global, gxmin, gxmax, bc_left, bc_right,
+                             M, n_colloc, gamma, W);
+  if (rc != LSSVR_OK) return rc;
+  rc = set_rhs(a, rhs_id, rhs_params_host, rhs_values, true, "ne");
+  if (rc != LSSVR_OK) return rc;
+  a.status = status;
+  a.fail_count = fail_count;
+  if (solver_id != LSSVR_SOLVER_PRIMAL && solver_id != LSSVR_SOLVER_DUAL &&
+      solver_id != LSSVR_SOLVER_PRIMAL_WAVE && solver_id != LSSVR_SOLVER_PRIMAL_MOMENT)
+    return fail(LSSVR_ERR_SOLVER, "unknown solver_id %d", solver_id);
+  if (work_bytes < 0 || (work_bytes > 0 && !work)) return fail(LSSVR_ERR_NULL, "work / work_bytes inconsistent");
+  const int64_t need = lssvr_enhance_work_bytes(ne, M, n_colloc, solver_id);
+  if (work && work_bytes < need)
+    return fail(LSSVR_ERR_SIZE, "work holds %lld bytes, lssvr_enhance_work_bytes() = %lld", (long long)work_bytes,
+                (long long)need);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  std::vector<lssvr::LaunchOpts> ev((size_t)repeats);
+  int made = 0;
+  for (; made < repeats; ++made)
+    if (hipEventCreate(&ev[made].start) != hipSuccess || hipEventCreate(&ev[made].stop) != hipSuccess) break;
+  rc = made == repeats ? LSSVR_OK : fail(LSSVR_ERR_LAUNCH, "hipEventCreate failed");
+  for (int r = 0; r < repeats && rc == LSSVR_OK; ++r) rc = enhance_dispatch(a, solver_id, s, &ev[r], work, work_bytes);
+  hipError_t e = hipStreamSynchronize(s);            // (also after a failed launch: earlier ones are in flight)
+  if (rc == LSSVR_OK && e != hipSuccess) rc = fail(LSSVR_ERR_LAUNCH, "profiled sequence: %s", hipGetErrorString(e));
+  for (int r = 0; r < repeats && rc == LSSVR_OK; ++r) {
+    e = hipEventElapsedTime(&kernel_ms_host[r], ev[r].start, ev[r].stop);
+    if (e != hipSuccess) rc = fail(LSSVR_ERR_LAUNCH, "profiled sequence: %s", hipGetErrorString(e));
+  }
+  for (int r = 0; r < repeats; ++r) {
+    if (ev[r].start) (void)hipEventDestroy(ev[r].start);
+    if (ev[r].stop) (void)hipEventDestroy(ev[r].stop);
+  }
+  return rc;
 }
 
 int lssvr_enhance_profiled(const double* x, const double* u, int64_t ne, int64_t elem_offset,

@@ -296,10 +296,12 @@ def enhance_shared(x, u, op, M, n_colloc, *, rhs=(POISSON_AMP, POISSON_OMEGA), r
 
 def enhance_profiled(x, u, M, gamma, n_colloc=12, *, rhs=(POISSON_AMP, POISSON_OMEGA),
                      elem_offset=0, ne_global=None, global_domain, bc=(0.0, 0.0),
-                     solver=SOLVER_PRIMAL, out=None, status=None, stream=None, work=None):
+                     solver=SOLVER_PRIMAL, out=None, status=None, stream=None, work=None, repeats=None):
     """Same launch as :func:`enhance` but BLOCKING and stamped with the dispatch's own
     begin/end timestamps; returns the kernel duration in seconds (roofline measurement; on the
-    two-kernel path above M = 22 the duration of the pair, gap included)."""
+    two-kernel path above M = 22 the duration of the pair, gap included).  ``repeats=k``: k launches
+    back to back, one synchronisation at the end (``lssvr_enhance_ws_sequence``): the list of the k
+    durations inside a running sequence instead of one duration in isolation."""
     import ctypes
     lib = _capi.load()
     _dev(x, "x")
@@ -315,6 +317,17 @@ def enhance_profiled(x, u, M, gamma, n_colloc=12, *, rhs=(POISSON_AMP, POISSON_O
         work = workspace(lib, x.device, ne, M, n_colloc, solver, stream)
     elif work is False:
         work = None
+    if repeats is not None:
+        arr = (ctypes.c_float * int(repeats))()
+        rc = lib.lssvr_enhance_ws_sequence(_ptr(x), _ptr(u), ne, int(elem_offset), int(ne_global),
+                                           float(global_domain[0]), float(global_domain[1]),
+                                           float(bc[0]), float(bc[1]), int(M), int(n_colloc), float(gamma),
+                                           RHS_SIN, _capi.rhs_params(*rhs), None, int(solver),
+                                           _ptr(out), _ptr(status), None,
+                                           _ptr(work), 0 if work is None else work.numel() * 8, _stream(stream),
+                                           int(repeats), arr)
+        _capi.check(rc, "lssvr_enhance_ws_sequence")
+        return [v * 1e-3 for v in arr]
     rc = lib.lssvr_enhance_ws(_ptr(x), _ptr(u), ne, int(elem_offset), int(ne_global),
                               float(global_domain[0]), float(global_domain[1]),
                               float(bc[0]), float(bc[1]), int(M), int(n_colloc), float(gamma),

@@ -159,6 +159,23 @@ int lssvr_enhance_ws(const double* x, const double* u, int64_t ne,
                      void* work, int64_t work_bytes, void* stream, float* kernel_ms_host);
 
 /*
+ * lssvr_enhance_ws_sequence -- `repeats` launches of lssvr_enhance_ws back to back on `stream`, each
+ * stamped with its own begin / end timestamps (what rocprofv3 --kernel-trace reports per dispatch), ONE
+ * synchronisation at the end: the duration of the launch INSIDE a running sequence, where
+ * lssvr_enhance_profiled measures it in isolation (an idle chip before and after).  BLOCKING measurement
+ * aid for bench.py's roofline.  kernel_ms_host: float[repeats] on the host.
+ */
+int lssvr_enhance_ws_sequence(const double* x, const double* u, int64_t ne,
+                              int64_t elem_offset, int64_t ne_global,
+                              double gxmin, double gxmax, double bc_left, double bc_right,
+                              int M, int n_colloc, double gamma,
+                              int rhs_id, const double* rhs_params_host, const double* rhs_values,
+                              int solver_id,
+                              double* W, int32_t* status, int32_t* fail_count,
+                              void* work, int64_t work_bytes, void* stream,
+                              int repeats, float* kernel_ms_host);
+
+/*
  * lssvr_enhance_profiled -- the same launch as lssvr_enhance, stamped with the
  * dispatch's own begin/end timestamps (hipExtLaunchKernelGGL).  BLOCKING: waits for
  * the kernel and returns its duration in *kernel_ms_host.  Measurement aid for
