@@ -276,6 +276,14 @@ def test_fused_step_equals_separate_launches(dev):
     dt = ops.enhance_profiled(x, u, M, 1e4, n, elem_offset=7, ne_global=ne + 20,
                               global_domain=(-3.0, 2.0), out=W3)
     assert torch.equal(W3, W2) and 1e-7 < dt < 1e-2
+    # lssvr_enhance_ws_sequence: k stamped launches back to back, one synchronisation; same result
+    W3.zero_()
+    dts = ops.enhance_profiled(x, u, M, 1e4, n, elem_offset=7, ne_global=ne + 20,
+                               global_domain=(-3.0, 2.0), out=W3, repeats=5)
+    assert len(dts) == 5 and all(1e-7 < t < 1e-2 for t in dts) and torch.equal(W3, W2)
+    from hybrid_fem_lssvr_amd import _capi
+    with pytest.raises(_capi.LssvrHipError):
+        ops.enhance_profiled(x, u, M, 1e4, n, global_domain=(-3.0, 2.0), out=W3, repeats=0)
 
 
 def test_varcoef_config5_full_size(dev, note):
