@@ -1059,7 +1059,7 @@ def run_single(args, D, M, n, ne_glob, lo, hi, dev, cpu_res, use_dist):
 
     # the same K steps issued round-robin on two HIP streams with separate output buffers: at
     # 1e5 elements one launch fills only ~60 % of the chip's wave slots, so independent batches
-    # overlap.  Reported beside `value` (which stays the strictly sequential single-stream rate).
+    # overlap.  Reported beside `value` (which is strictly sequential on one stream).
     pipelined = None
     if args.solver == "primal":
         try:
