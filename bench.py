@@ -829,8 +829,12 @@ def run_config5(args, D, M, n, ne, lo, hi, dev, cpu_res):
         except Exception as exc:  # pragma: no cover
             eager_loop = {"error": repr(exc)}
     n_fallback = int(w["st"].sum().item())
-    k_s = sorted(enh(w, profiled=True) for _ in range(min(steps, 50)))
+    # the kernel's stamped duration inside a running sequence (as in the timed region); isolated beside it
+    nprof = min(steps, 50)
+    enh(w, profiled=True, repeats=max(nprof, 20))                               # (untimed: steady state)
+    k_s = sorted(enh(w, profiled=True, repeats=nprof))
     k_avg, k_med = sum(k_s) / len(k_s), k_s[len(k_s) // 2]
+    k_iso = sorted(enh(w, profiled=True) for _ in range(min(steps, 20)))
 
     # the other table layout on the same mesh (same values transposed; bit-equal W expected)
     other = None
@@ -951,6 +955,9 @@ def run_config5(args, D, M, n, ne, lo, hi, dev, cpu_res):
             "bytes_per_element": byts,
             "elements_per_launch": ne,
             "kernel_us_avg": k_avg * 1e6,
+            "kernel_us_isolated_avg": sum(k_iso) / len(k_iso) * 1e6,
+            "kernel_us_is": "average over %d launches issued back to back, each with its own begin -> end stamps, one "
+                            "synchronisation at the end (kernel_us_isolated_avg: a synchronisation around every launch)" % nprof,
             "kernel_us_median": k_med * 1e6,
             "traffic": None,
             "traffic_source": None,

@@ -76,6 +76,12 @@ SIGNATURES = {
                                           _c_int, _c_int, _c_dbl,
                                           _c_dp, _c_dp, _c_dp, _c_int,
                                           _c_dp, _c_dp, _c_dp, _c_dp, _c_i64, _c_dp, C.POINTER(C.c_float)]),
+    "lssvr_enhance_varcoef_ws_sequence": (_c_int, [_c_dp, _c_dp, _c_i64, _c_i64, _c_i64,
+                                                   _c_dbl, _c_dbl, _c_dbl, _c_dbl,
+                                                   _c_int, _c_int, _c_dbl,
+                                                   _c_dp, _c_dp, _c_dp, _c_int,
+                                                   _c_dp, _c_dp, _c_dp, _c_dp, _c_i64, _c_dp,
+                                                   _c_int, C.POINTER(C.c_float)]),
     "lssvr_step_varcoef": (_c_int, [_c_dp, _c_dp, _c_i64, _c_i64, _c_i64,
                                     _c_dbl, _c_dbl, _c_dbl, _c_dbl,
                                     _c_int, _c_int, _c_dbl,

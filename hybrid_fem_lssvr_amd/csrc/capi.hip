@@ -144,6 +144,31 @@ int dispatch_timed(const lssvr::EnhanceArgs& a, int solver_id, hipStream_t s, vo
 }
 }  // namespace
 
+namespace {
+// `repeats` launches of enhance_dispatch back to back, each with its own begin / end stamps, ONE
+// synchronisation at the end (lssvr_enhance_ws_sequence, lssvr_enhance_varcoef_ws_sequence)
+int dispatch_sequence(const lssvr::EnhanceArgs& a, int solver_id, hipStream_t s, void* work, int64_t work_bytes,
+                      int repeats, float* kernel_ms_host) {
+  std::vector<lssvr::LaunchOpts> ev((size_t)repeats);
+  int made = 0;
+  for (; made < repeats; ++made)
+    if (hipEventCreate(&ev[made].start) != hipSuccess || hipEventCreate(&ev[made].stop) != hipSuccess) break;
+  int rc = made == repeats ? LSSVR_OK : fail(LSSVR_ERR_LAUNCH, "hipEventCreate failed");
+  for (int r = 0; r < repeats && rc == LSSVR_OK; ++r) rc = enhance_dispatch(a, solver_id, s, &ev[r], work, work_bytes);
+  hipError_t e = hipStreamSynchronize(s);            // (also after a failed launch: earlier ones are in flight)
+  if (rc == LSSVR_OK && e != hipSuccess) rc = fail(LSSVR_ERR_LAUNCH, "profiled sequence: %s", hipGetErrorString(e));
+  for (int r = 0; r < repeats && rc == LSSVR_OK; ++r) {
+    e = hipEventElapsedTime(&kernel_ms_host[r], ev[r].start, ev[r].stop);
+    if (e != hipSuccess) rc = fail(LSSVR_ERR_LAUNCH, "profiled sequence: %s", hipGetErrorString(e));
+  }
+  for (int r = 0; r < repeats; ++r) {
+    if (ev[r].start) (void)hipEventDestroy(ev[r].start);
+    if (ev[r].stop) (void)hipEventDestroy(ev[r].stop);
+  }
+  return rc;
+}
+}  // namespace
+
 extern "C" {
 
 int lssvr_version(void) { return LSSVR_ABI_VERSION; }
@@ -231,24 +256,8 @@ int lssvr_enhance_ws_sequence(const double* x, const double* u, int64_t ne, int6
   if (work && work_bytes < need)
     return fail(LSSVR_ERR_SIZE, "work holds %lld bytes, lssvr_enhance_work_bytes() = %lld", (long long)work_bytes,
                 (long long)need);
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  std::vector<lssvr::LaunchOpts> ev((size_t)repeats);
-  int made = 0;
-  for (; made < repeats; ++made)
-    if (hipEventCreate(&ev[made].start) != hipSuccess || hipEventCreate(&ev[made].stop) != hipSuccess) break;
-  rc = made == repeats ? LSSVR_OK : fail(LSSVR_ERR_LAUNCH, "hipEventCreate failed");
-  for (int r = 0; r < repeats && rc == LSSVR_OK; ++r) rc = enhance_dispatch(a, solver_id, s, &ev[r], work, work_bytes);
-  hipError_t e = hipStreamSynchronize(s);            // (also after a failed launch: earlier ones are in flight)
-  if (rc == LSSVR_OK && e != hipSuccess) rc = fail(LSSVR_ERR_LAUNCH, "profiled sequence: %s", hipGetErrorString(e));
-  for (int r = 0; r < repeats && rc == LSSVR_OK; ++r) {
-    e = hipEventElapsedTime(&kernel_ms_host[r], ev[r].start, ev[r].stop);
-    if (e != hipSuccess) rc = fail(LSSVR_ERR_LAUNCH, "profiled sequence: %s", hipGetErrorString(e));
-  }
-  for (int r = 0; r < repeats; ++r) {
-    if (ev[r].start) (void)hipEventDestroy(ev[r].start);
-    if (ev[r].stop) (void)hipEventDestroy(ev[r].stop);
-  }
-  return rc;
+  return dispatch_sequence(a, solver_id, reinterpret_cast<hipStream_t>(stream), work, work_bytes, repeats,
+                           kernel_ms_host);
 }
 
 int lssvr_enhance_profiled(const double* x, const double* u, int64_t ne, int64_t elem_offset,
@@ -415,6 +424,43 @@ int lssvr_enhance_varcoef_ws(const double* x, const double* u, int64_t ne, int64
   // (n_colloc < M-2: rank-deficient primal normal equations -> the dual Gram solver)
   return dispatch_timed(a, LSSVR_SOLVER_PRIMAL, reinterpret_cast<hipStream_t>(stream), work, work_bytes,
                         kernel_ms_host);
+}
+
+int lssvr_enhance_varcoef_ws_sequence(const double* x, const double* u, int64_t ne, int64_t elem_offset,
+                                      int64_t ne_global, double gxmin, double gxmax, double bc_left,
+                                      double bc_right, int M, int n_colloc, double gamma,
+                                      const double* a_values, const double* da_values,
+                                      const double* rhs_values, int table_layout, double* W, int32_t* status,
+                                      int32_t* fail_count, void* work, int64_t work_bytes, void* stream,
+                                      int repeats, float* kernel_ms_host) {
+  if (!kernel_ms_host) return fail(LSSVR_ERR_NULL, "kernel_ms_host must be non-NULL (float[repeats])");
+  if (repeats < 1 || repeats > 100000) return fail(LSSVR_ERR_SIZE, "repeats = %d outside [1, 100000]", repeats);
+  if (ne < 1) return fail(LSSVR_ERR_SIZE, "nothing to profile: ne = %lld", (long long)ne);
+  lssvr::EnhanceArgs a;
+  int rc = fill_enhance_args(a, x, u, ne, elem_offset, ne_global, gxmin, gxmax, bc_left, bc_right,
+                             M, n_colloc, gamma, W);
+  if (rc != LSSVR_OK) return rc;
+  if (!a_values || !da_values || !rhs_values)
+    return fail(LSSVR_ERR_NULL, "a_values, da_values and rhs_values must be non-NULL");
+  if (table_layout != LSSVR_TABLE_ELEMENT_MAJOR && table_layout != LSSVR_TABLE_POINT_MAJOR)
+    return fail(LSSVR_ERR_SIZE, "unknown table_layout %d", table_layout);
+  a.rhs_id = LSSVR_RHS_ARRAY;
+  a.rhs_values = rhs_values;
+  a.a_values = a_values;
+  a.da_values = da_values;
+  if (table_layout == LSSVR_TABLE_POINT_MAJOR) {
+    a.tab_es = 1;
+    a.tab_ps = ne;
+  }
+  a.status = status;
+  a.fail_count = fail_count;
+  if (work_bytes < 0 || (work_bytes > 0 && !work)) return fail(LSSVR_ERR_NULL, "work / work_bytes inconsistent");
+  const int64_t need = lssvr_enhance_varcoef_work_bytes(ne, M, n_colloc);
+  if (work && work_bytes < need)
+    return fail(LSSVR_ERR_SIZE, "work holds %lld bytes, lssvr_enhance_varcoef_work_bytes() = %lld",
+                (long long)work_bytes, (long long)need);
+  return dispatch_sequence(a, LSSVR_SOLVER_PRIMAL, reinterpret_cast<hipStream_t>(stream), work, work_bytes,
+                           repeats, kernel_ms_host);
 }
 
 int lssvr_enhance_subset(const double* x, const double* u, int64_t ne_mesh,

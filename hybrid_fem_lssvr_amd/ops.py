@@ -405,10 +405,11 @@ class StepPlan:
 
 def enhance_varcoef(x, u, M, gamma, n_colloc, a_values, da_values, rhs_values, *, elem_offset=0,
                     ne_global=None, global_domain=None, bc=(0.0, 0.0), out=None, status=None,
-                    fail_count=None, stream=None, profiled=False, point_major=False):
+                    fail_count=None, stream=None, profiled=False, point_major=False, repeats=None):
     """BASELINE config 5: rows -a (2/h)^2 L'' - a' (2/h) L' (no reference counterpart; the
     operator it generalises is Dual.py:43-44).  ``profiled``: BLOCKING, returns the launch
-    duration in seconds (the dispatch's own begin / end stamps) instead of (W, status).
+    duration in seconds (the dispatch's own begin / end stamps) instead of (W, status); with
+    ``repeats=k`` the list of the durations of k launches back to back, one synchronisation at the end.
     ``point_major``: the three tables are float64[n_colloc, ne] (``t[k, e]``) instead of
     float64[ne, n_colloc] -- see :func:`colloc_points`; the fast layout for M <= 22."""
     import ctypes
@@ -429,6 +430,15 @@ def enhance_varcoef(x, u, M, gamma, n_colloc, a_values, da_values, rhs_values, *
         raise ValueError("x and u must be 1-D with equal length ne+1")
     out, status = _check_buffers(ne, M, n_colloc, x, out=out, status=status, fail_count=fail_count)
     ms = ctypes.c_float(0.0)
+    if profiled and repeats is not None:
+        arr = (ctypes.c_float * int(repeats))()
+        rc = lib.lssvr_enhance_varcoef_ws_sequence(
+            _ptr(x), _ptr(u), ne, int(elem_offset), int(ne_global), float(global_domain[0]), float(global_domain[1]),
+            float(bc[0]), float(bc[1]), int(M), int(n_colloc), float(gamma), _ptr(a_values), _ptr(da_values),
+            _ptr(rhs_values), TABLE_POINT_MAJOR if point_major else TABLE_ELEMENT_MAJOR, _ptr(out), _ptr(status),
+            _ptr(fail_count), None, 0, _stream(stream), int(repeats), arr)
+        _capi.check(rc, "lssvr_enhance_varcoef_ws_sequence")
+        return [v * 1e-3 for v in arr]
     rc = lib.lssvr_enhance_varcoef_ws(_ptr(x), _ptr(u), ne, int(elem_offset), int(ne_global),
                                       float(global_domain[0]), float(global_domain[1]),
                                       float(bc[0]), float(bc[1]), int(M), int(n_colloc), float(gamma),

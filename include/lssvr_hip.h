@@ -175,6 +175,17 @@ int lssvr_enhance_ws_sequence(const double* x, const double* u, int64_t ne,
                               void* work, int64_t work_bytes, void* stream,
                               int repeats, float* kernel_ms_host);
 
+/* The same for lssvr_enhance_varcoef_ws (BASELINE config 5). */
+int lssvr_enhance_varcoef_ws_sequence(const double* x, const double* u, int64_t ne,
+                                      int64_t elem_offset, int64_t ne_global,
+                                      double gxmin, double gxmax, double bc_left, double bc_right,
+                                      int M, int n_colloc, double gamma,
+                                      const double* a_values, const double* da_values,
+                                      const double* rhs_values, int table_layout,
+                                      double* W, int32_t* status, int32_t* fail_count,
+                                      void* work, int64_t work_bytes, void* stream,
+                                      int repeats, float* kernel_ms_host);
+
 /*
  * lssvr_enhance_profiled -- the same launch as lssvr_enhance, stamped with the
  * dispatch's own begin/end timestamps (hipExtLaunchKernelGGL).  BLOCKING: waits for
