@@ -76,6 +76,18 @@ constexpr ChebDeviceTables make_cheb_device_tables() {
 
 __device__ const ChebDeviceTables kTab = make_cheb_device_tables();
 
+// X = Y^-1 (rho_j = sum_i X[i][j] T_i), zero padded: the ridge-dominated cold path only
+struct ChebInverseTable {
+  double X[32][32];
+};
+constexpr ChebInverseTable make_cheb_inverse_table() {
+  ChebInverseTable t{};
+  for (int i = 0; i < 31; ++i)
+    for (int j = 0; j < 31; ++j) t.X[i][j] = cheb::kX[i][j];
+  return t;
+}
+__device__ const ChebInverseTable kInv = make_cheb_inverse_table();
+
 }  // namespace
 
 
@@ -129,6 +141,7 @@ __device__ __forceinline__ void solve_four(const EnhanceArgs& p, const int lane,
     const double hh = 0.5 * dm.oldlen;
     const double inv_scl2 = hh * hh;
     const double eps2 = (2.0 * inv_gamma) * (inv_scl2 * inv_scl2);
+    if (ridge_dominated(eps2, M)) live = false;       // solved by moments_kernel (ridge_wave_solve)
 
     // ---- boundary rows to first order (enhance_small_cheb.hpp); exact recurrence when the wave
     // holds an element beyond the first-order range
@@ -335,6 +348,125 @@ __device__ __forceinline__ void solve_four(const EnhanceArgs& p, const int lane,
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// RIDGE-DOMINATED element (lssvr_device.hpp::ridge_dominated): the whole solve of ONE element by the
+// wave that accumulated its moments, in the Legendre-bubble basis (the lane kernel's cheb_ridge_solve,
+// wave-cooperative):  S2_v = X^T (m_{i+k} + m_{|i-k|}) X + eps2 (I + C^T C),  rhs2_v = X^T r2 + eps2 C^T d,
+// exact boundary rows, LDL^T and the substitutions in the wave's LDS tile, then W / status of the element.
+// The solve kernels skip such elements (same predicate).  Cold: coarse elements with a small gamma only.
+//   rec: the element's 96 workspace numbers (global, written by this wave);  tl: >= 1216 doubles of LDS.
+// ---------------------------------------------------------------------------------------------
+// (Scalars instead of the EnhanceArgs: a reference would put the kernel's whole argument block on its stack.)
+__device__ __attribute__((noinline)) void ridge_wave_solve(double* __restrict__ Wrow, int32_t* __restrict__ status,
+                                                           int32_t* __restrict__ fail_count, const int M,
+                                                           const double* __restrict__ rec,
+                                                           double* __restrict__ tl, const int lane,
+                                                           const double eps2) {
+  constexpr int kP = 33;                       // row pitch of the matrix
+  const int MR = M - 2;
+  double* const mo = tl;                       // m_0..m_60 | a b g_l | r_0..r_30 | g_r
+  double* const c0 = tl + 96;
+  double* const c1 = tl + 128;
+  double* const xr = tl + 160;
+  double* const S = tl + 192;
+  wave_lds_sync();
+  // (system-scope loads: the rows were stored write-through by other lanes of this wave)
+  mo[lane] = __hip_atomic_load(rec + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (lane < 32) mo[64 + lane] = __hip_atomic_load(rec + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  wave_lds_sync();
+  const double a = mo[61], b = mo[62], gl = mo[63], gr = mo[95];
+  const DomainMap dm = map_params(a, b);
+  const double ta = dm.off + dm.scl * a;
+  const double tb = dm.off + dm.scl * b;
+  const double idet = 1.0 / (tb - ta);
+  const double d0 = (tb * gl - ta * gr) * idet;
+  const double d1 = (gr - gl) * idet;
+  if (lane == 0) {                             // exact boundary rows: L_{j+2}(ta), L_{j+2}(tb)
+    double am1 = 1.0, a0 = ta, bm1 = 1.0, b0 = tb;
+    for (int pp = 1; pp < M - 1; ++pp) {
+      const double inv = 1.0 / (double)(pp + 1);
+      const double a1 = ((double)(2 * pp + 1) * ta * a0 - (double)pp * am1) * inv;
+      const double b1 = ((double)(2 * pp + 1) * tb * b0 - (double)pp * bm1) * inv;
+      am1 = a0; a0 = a1;
+      bm1 = b0; b0 = b1;
+      c0[pp - 1] = (tb * a1 - ta * b1) * idet;
+      c1[pp - 1] = (b1 - a1) * idet;
+    }
+  }
+  // A = G2 X  (G2[i][k] = m_{i+k} + m_{|i-k|}), every entry by one lane
+  for (int idx = lane; idx < MR * 32; idx += 64) {
+    const int i = idx >> 5, j = idx & 31;
+    if (j < MR) {
+      double s = 0.0;
+      for (int k = (j & 1); k <= j; k += 2) {
+        const int dk = i > k ? i - k : k - i;
+        s = fma(mo[i + k] + mo[dk], kInv.X[k][j], s);
+      }
+      S[i * kP + j] = s;
+    }
+  }
+  wave_lds_sync();
+  // S = X^T A + ridge in place: lane j owns column j (row i reads rows <= i of its own column only, so
+  // descending rows need no synchronisation);  rhs2_v likewise
+  if (lane < MR) {
+    const int j = lane;
+    const double c0j = c0[j], c1j = c1[j];
+    for (int i = MR - 1; i >= 0; --i) {
+      double s = 0.0;
+      for (int k = (i & 1); k <= i; k += 2) s = fma(kInv.X[k][i], S[k * kP + j], s);
+      double cc = fma(c0[i], c0j, c1[i] * c1j);
+      if (i == j) cc += 1.0;
+      S[i * kP + j] = fma(eps2, cc, s);
+    }
+    double r = 0.0;
+    for (int i = (j & 1); i <= j; i += 2) r = fma(kInv.X[i][j], mo[64 + i], r);
+    xr[j] = fma(eps2, fma(c0j, d0, c1j * d1), r);
+  }
+  wave_lds_sync();
+  // LDL^T (right-looking, lower part; unit L below the diagonal, the diagonal holds 1/d_j)
+  bool ok = true;
+  for (int j = 0; j < MR; ++j) {
+    const double dj = S[j * kP + j];
+    ok = ok && (dj > 0.0);
+    const double rinv = 1.0 / dj;
+    for (int idx = (j + 1) * 32 + lane; idx < MR * 32; idx += 64) {
+      const int i = idx >> 5, c = idx & 31;
+      if (c > j && c <= i) S[i * kP + c] = fma(-S[i * kP + j], S[c * kP + j] * rinv, S[i * kP + c]);
+    }
+    wave_lds_sync();
+    if (lane > j && lane < MR) S[lane * kP + j] *= rinv;
+    if (lane == 0) S[j * kP + j] = rinv;
+    wave_lds_sync();
+  }
+  for (int j = 0; j < MR - 1; ++j) {           // L y = rhs
+    const double xj = xr[j];
+    if (lane > j && lane < MR) xr[lane] = fma(-S[lane * kP + j], xj, xr[lane]);
+    wave_lds_sync();
+  }
+  if (lane < MR) xr[lane] *= S[lane * kP + lane];
+  wave_lds_sync();
+  for (int j = MR - 1; j > 0; --j) {           // L^T v = D^-1 y
+    const double vj = xr[j];
+    if (lane < j) xr[lane] = fma(-S[j * kP + lane], vj, xr[lane]);
+    wave_lds_sync();
+  }
+  const double v = lane < MR ? xr[lane] : 0.0;
+  double w0 = d0, w1 = d1;
+  for (int j = 0; j < MR; ++j) {               // (every lane the same sum, in order)
+    w0 = fma(-c0[j], xr[j], w0);
+    w1 = fma(-c1[j], xr[j], w1);
+  }
+  ok = ok && !__any(!(fabs(v) < 1.0e300)) && (fabs(w0) < 1.0e300) && (fabs(w1) < 1.0e300);
+  if (lane < MR) Wrow[lane + 2] = ok ? v : 0.0;
+  if (lane == 0) {
+    Wrow[0] = ok ? w0 : 0.5 * (gl + gr);
+    Wrow[1] = ok ? w1 : 0.5 * (gr - gl);
+    if (status) *status = ok ? LSSVR_ST_OK : LSSVR_ST_FALLBACK;
+    if (!ok && fail_count) atomicAdd(fail_count, 1);
+  }
+  wave_lds_sync();
+}
+
 // =============================================================================================
 // The same two phases as TWO kernels with a caller-provided workspace in between (96 doubles per
 // element: lssvr_enhance_work_bytes): the solve kernel then holds nothing but the two columns per
@@ -465,6 +597,44 @@ __global__ __launch_bounds__(kMomBlock, 2) void moments_kernel(EnhanceArgs p, do
                            __HIP_MEMORY_SCOPE_SYSTEM);
     }
   });
+  // ---- ridge-dominated elements (coarse elements with a small gamma; none on a BASELINE mesh): the wave
+  // solves them here, one at a time, in the Legendre-bubble basis, and the solve kernels skip them.
+  // Everything the test needs is RECOMPUTED from memory behind an opaque thread index, so that nothing
+  // stays live across the accumulation loop for it (kept live, id / h / the flag cost the loop 33 spills).
+  {
+    unsigned tx = threadIdx.x;
+    asm volatile("" : "+v"(tx));
+    const int64_t e2 = (int64_t)blockIdx.x * kMomBlock + tx;
+    bool valid = e2 < p.ne;
+    int64_t id2 = valid ? e2 : p.ne - 1;
+    if (p.elem_ids) {
+      id2 = p.elem_ids[id2];
+      if (id2 < 0 || id2 >= p.ne_mesh) {     // (counted by the solve kernel)
+        id2 = 0;
+        valid = false;
+      }
+    }
+    const double h2 = 0.5 * (p.x[id2 + 1] - p.x[id2]);
+    const double is2 = h2 * h2;
+    const double inv_gamma = p.gamma_values ? rcp_newton(p.gamma_values[id2]) : p.inv_gamma;
+    const double eps2 = (2.0 * inv_gamma) * (is2 * is2);               // the solve kernels' expression
+    unsigned long long rmask = __ballot(valid && ridge_dominated(eps2, p.M));
+    if (rmask) {
+      __atomic_thread_fence(__ATOMIC_SEQ_CST);         // the wave's workspace rows are written
+      const int ln = tx & 63;
+      double* const tile = mtile + (tx >> 6) * (64 * 33);
+      const int64_t w0 = e2 - ln;                      // the wave's first element
+      while (rmask) {
+        const int t = __builtin_ctzll(rmask);
+        rmask &= rmask - 1;
+        const unsigned long long idt =
+            __builtin_bit_cast(unsigned long long, readlane_f64(__builtin_bit_cast(double, (unsigned long long)id2), t));
+        const int64_t idm = (int64_t)idt;
+        ridge_wave_solve(p.W + idm * (p.ldw ? p.ldw : (int64_t)p.M), p.status ? p.status + idm : nullptr,
+                         p.fail_count, p.M, ws + (w0 + t) * kWsStride, tile, ln, readlane_f64(eps2, t));
+      }
+    }
+  }
 }
 
 // Phase 2 alone: a workgroup of four waves = sixteen elements (four per wave); the moments come

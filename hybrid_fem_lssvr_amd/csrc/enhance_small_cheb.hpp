@@ -29,6 +29,15 @@
 // (alpha, b, N of cheb_tables.hpp) with its first-order terms in sigma / delta.
 // The whole system is carried scaled by 2 (S2 = m_{i+k} + m_{|i-k|} + 2 eps R) so that the 1/2
 // of the product formula costs nothing.
+//
+// RIDGE-DOMINATED elements (gamma scl^4 below ridge_gamma_scl4(M), lssvr_device.hpp: coarse elements with a small gamma;
+// no BASELINE configuration).  In the Chebyshev basis the ridge is eps (N + C_z^T C_z), N = Y^T Y, and
+// once eps outweighs the Gram the solve inherits cond(Y)^2 (measured against the 60-digit minimiser,
+// round 3's finding: 3e-13 at M = 9, 3e-11 at M = 22, where the float64 KKT solve holds 1e-15).  A wave
+// with such an element runs cheb_ridge_solve: the SAME moments, mapped back to the Legendre-bubble
+// basis, G_v = X^T G_T X (X = Y^-1 >= 0, exact table), where the ridge is eps (I + C^T C) again -- the
+// accuracy of the direct Gram in that regime (<= 3e-15) at no cost to the hot path (out of line, on
+// the cold path's scratch; numpy prototype scripts/proto/cheb_moment.py::solve_ridge_kernel).
 #pragma once
 #include "cheb_tables.hpp"
 #include "lssvr_device.hpp"
@@ -71,7 +80,8 @@ struct ChebSlow {
   static constexpr int kC1 = kC0 + MR;
   static constexpr int kZ0 = kC1 + MR;              // work: C_z = C Y
   static constexpr int kZ1 = kZ0 + MR;
-  static constexpr int kSize = kZ1 + MR;
+  static constexpr int kRes = kZ1 + MR;             // cheb_ridge_solve's result: w[M]
+  static constexpr int kSize = kRes + M;
 };
 
 template <int M>
@@ -119,6 +129,106 @@ __device__ __attribute__((noinline)) void cheb_slow_build(double* __restrict__ b
     }
     buf[L::kRhs + i] = fma(eps2, fma(z0, d0, z1 * d1), buf[L::kRhs + i]);
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Cold path of a wave with a RIDGE-DOMINATED element (header comment): from the same moments and
+// right-hand side, the system in the Legendre-bubble basis
+//     S2_v = X^T (m_{i+k} + m_{|i-k|}) X + eps2 (I + C^T C),   rhs2_v = X^T r2 + eps2 C^T d
+// with the exact boundary rows (Legendre recurrence, as cheb_slow_build), LDL^T and the two
+// substitutions, all with run-time loops on the per-lane scratch buffer.  In: buf[kMom], buf[kRhs];
+// out: buf[kRes .. kRes + M) = w; returns whether every pivot was positive.
+// ---------------------------------------------------------------------------------------------
+template <int M>
+__device__ __attribute__((noinline)) bool cheb_ridge_solve(double* __restrict__ buf, double ta,
+                                                           double tb, double gl, double gr,
+                                                           double eps2) {
+  using L = ChebSlow<M>;
+  constexpr int MR = L::MR;
+  const double idet = 1.0 / (tb - ta);
+  const double d0 = (tb * gl - ta * gr) * idet;
+  const double d1 = (gr - gl) * idet;
+  double am1 = 1.0, a0 = ta, bm1 = 1.0, b0 = tb;
+#pragma nounroll
+  for (int pp = 1; pp < M - 1; ++pp) {
+    const double inv = 1.0 / (double)(pp + 1);
+    const double a1 = ((double)(2 * pp + 1) * ta * a0 - (double)pp * am1) * inv;
+    const double b1 = ((double)(2 * pp + 1) * tb * b0 - (double)pp * bm1) * inv;
+    am1 = a0; a0 = a1;
+    bm1 = b0; b0 = b1;
+    buf[L::kC0 + pp - 1] = (tb * a1 - ta * b1) * idet;
+    buf[L::kC1 + pp - 1] = (b1 - a1) * idet;
+  }
+  // rhs2_v = X^T r2 (in place, descending: entry j reads entries <= j only) + eps2 C^T d
+#pragma nounroll
+  for (int j = MR - 1; j >= 0; --j) {
+    double s = 0.0;
+#pragma nounroll
+    for (int i = (j & 1); i <= j; i += 2) s = fma(cheb::kX[i][j], buf[L::kRhs + i], s);
+    buf[L::kRhs + j] = fma(eps2, fma(buf[L::kC0 + j], d0, buf[L::kC1 + j] * d1), s);
+  }
+  // S2_v column by column: a = G2 X[:, j] (kZ0, MR entries), then S[i][j] = X[:, i] . a, i >= j
+#pragma nounroll
+  for (int j = 0; j < MR; ++j) {
+#pragma nounroll
+    for (int i = 0; i < MR; ++i) {
+      double s = 0.0;
+#pragma nounroll
+      for (int k = (j & 1); k <= j; k += 2) {
+        const int dk = i > k ? i - k : k - i;
+        s = fma(buf[L::kMom + i + k] + buf[L::kMom + dk], cheb::kX[k][j], s);
+      }
+      buf[L::kZ0 + i] = s;
+    }
+    const double c0j = buf[L::kC0 + j], c1j = buf[L::kC1 + j];
+#pragma nounroll
+    for (int i = j; i < MR; ++i) {
+      double s = 0.0;
+#pragma nounroll
+      for (int k = (i & 1); k <= i; k += 2) s = fma(cheb::kX[k][i], buf[L::kZ0 + k], s);
+      double cc = fma(buf[L::kC0 + i], c0j, buf[L::kC1 + i] * c1j);
+      if (i == j) cc += 1.0;
+      buf[L::kS + tri(i, j)] = fma(eps2, cc, s);
+    }
+  }
+  // LDL^T in place (unit L below the diagonal, the diagonal holds 1/d_j), then L y = rhs, L^T v = D^-1 y
+  bool ok = true;
+#pragma nounroll
+  for (int j = 0; j < MR; ++j) {
+    const double dj = buf[L::kS + tri(j, j)];
+    ok = ok && (dj > 0.0);
+    const double rinv = 1.0 / dj;
+    buf[L::kS + tri(j, j)] = rinv;
+#pragma nounroll
+    for (int c = j + 1; c < MR; ++c) {
+      const double lcj = buf[L::kS + tri(c, j)] * rinv;
+#pragma nounroll
+      for (int i = c; i < MR; ++i)
+        buf[L::kS + tri(i, c)] = fma(-buf[L::kS + tri(i, j)], lcj, buf[L::kS + tri(i, c)]);
+      buf[L::kS + tri(c, j)] = lcj;
+    }
+  }
+#pragma nounroll
+  for (int i = 0; i < MR; ++i) {
+    double s = buf[L::kRhs + i];
+#pragma nounroll
+    for (int j = 0; j < i; ++j) s = fma(-buf[L::kS + tri(i, j)], buf[L::kRhs + j], s);
+    buf[L::kRhs + i] = s;
+  }
+  double w0 = d0, w1 = d1;
+#pragma nounroll
+  for (int i = MR - 1; i >= 0; --i) {
+    double s = buf[L::kRhs + i] * buf[L::kS + tri(i, i)];
+#pragma nounroll
+    for (int j = i + 1; j < MR; ++j) s = fma(-buf[L::kS + tri(j, i)], buf[L::kRhs + j], s);
+    buf[L::kRhs + i] = s;
+    buf[L::kRes + 2 + i] = s;
+    w0 = fma(-buf[L::kC0 + i], s, w0);
+    w1 = fma(-buf[L::kC1 + i], s, w1);
+  }
+  buf[L::kRes] = w0;
+  buf[L::kRes + 1] = w1;
+  return ok;
 }
 
 // REFINE: the build with the near-square refinement loop (its own kernel, enhance_small_refine_kernel:
@@ -196,6 +306,10 @@ __device__ __forceinline__ void enhance_small_body_cheb(const EnhanceArgs& p, co
     // (a non-finite map -- degenerate element -- is not "slow": it ends in the status test)
     const bool slow = kAmax * fmax(fabs(ea), fabs(eb)) >= 1.0e-6;
     const bool any_slow = __any(slow);
+    // ridge-dominated element (header comment; NaN / inf end in the status test of either path)
+    const bool ridge = MR > 0 && ridge_dominated(eps2, M);
+    const bool any_ridge = __any(ridge);
+    [[maybe_unused]] bool ridge_ok = true;
     double d0 = (tb * gl - ta * gr) * idet;
     double d1 = (gr - gl) * idet;
 
@@ -350,6 +464,16 @@ __device__ __forceinline__ void enhance_small_body_cheb(const EnhanceArgs& p, co
       for (int d = 0; d < MR; ++d) mm[d] = mom[d];
 #pragma unroll
       for (int j = 1; j < MR; ++j) mm[MR - 1 + j] = fma(2.0, P[j], -mom[MR - 1 - j]);
+
+      // --- ridge-dominated elements: the wave also solves in the Legendre-bubble basis (cold) -----
+      if (any_ridge) {
+        using L = ChebSlow<M>;
+#pragma unroll
+        for (int d = 0; d < 2 * MR - 1; ++d) slowbuf[L::kMom + d] = mm[d];
+#pragma unroll
+        for (int i = 0; i < MR; ++i) slowbuf[L::kRhs + i] = rv[i];
+        ridge_ok = cheb_ridge_solve<M>(slowbuf, ta, tb, gl, gr, eps2);
+      }
 
       // --- S2 = m_{i+k} + m_{|i-k|} + 2 eps (N + C_z^T C_z),  rhs2 = r2 + 2 eps C_z^T d ----------
       double G[NT];
@@ -509,6 +633,16 @@ __device__ __forceinline__ void enhance_small_body_cheb(const EnhanceArgs& p, co
 #pragma unroll
           for (int i = 0; i < MR; ++i) rv[i] += rho[i];
           to_legendre();
+        }
+      }
+      if (any_ridge) {
+        // a ridge-dominated lane takes the cold path's result (the other lanes of the wave keep theirs)
+        if (ridge) {
+          ok = ridge_ok;
+          w0 = slowbuf[ChebSlow<M>::kRes];
+          w1 = slowbuf[ChebSlow<M>::kRes + 1];
+#pragma unroll
+          for (int j = 0; j < MR; ++j) w[j + 2] = slowbuf[ChebSlow<M>::kRes + 2 + j];
         }
       }
 #pragma unroll

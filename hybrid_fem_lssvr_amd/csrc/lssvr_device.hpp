@@ -295,4 +295,24 @@ __device__ __forceinline__ void legendre_p(double t, double (&L)[M]) {
 // packed lower-triangular index, j <= i
 __host__ __device__ constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }
 
+// ---------------------------------------------------------------------------
+// RIDGE-DOMINATED elements of the Chebyshev-moment kernels (Poisson rows): gamma scl^4 below
+// ridge_gamma_scl4(M), i.e. eps2 = 2 / (gamma scl^4) above ridge_eps2_threshold(M).  There the ridge
+// eps (N + C_z^T C_z), N = Y^T Y, outweighs the moment Gram and the solve in the Chebyshev basis
+// inherits cond(Y)^2 (3e-13 at M = 9, 3e-11 at M = 22, 6e-9 at M = 33 against the 60-digit minimiser,
+// where the float64 KKT solve holds 1e-15): such elements are solved in the Legendre-bubble basis
+// instead, from the same moments (cheb_ridge_solve / ridge_wave_solve).  The crossover of the two
+// forms' measured errors (scripts/proto/cheb_moment.py ridge_sweep: smooth and rough right-hand
+// sides) moves down with cond(Y_M)^2.  ONE predicate for every kernel: the two-kernel path relies
+// on moments_kernel and the solve kernels taking the same decision for an element.
+// ---------------------------------------------------------------------------
+__host__ __device__ constexpr double ridge_gamma_scl4(int M) {
+  return (M <= 12) ? 3.0e-4 : (M <= 17) ? 1.0e-4 : 3.0e-5;
+}
+__host__ __device__ constexpr double ridge_eps2_threshold(int M) { return 2.0 / ridge_gamma_scl4(M); }
+// (inf / NaN -- gamma = 0, a degenerate element -- are not "ridge": they end in the status test)
+__device__ __forceinline__ bool ridge_dominated(double eps2, int M) {
+  return eps2 > ridge_eps2_threshold(M) && eps2 < 1.0e300;
+}
+
 }  // namespace lssvr

@@ -100,7 +100,7 @@ def check(nodes, values, M, gamma, n, sel, gd=None):
         errs.append(orc.rel_l2_coef(w[None], tr[None])[0]); errs_o.append(orc.rel_l2_coef(wo[None], tr[None])[0])
     return max(errs), max(errs_o)
 
-if __name__ == "__main__":
+if __name__ == "__main__" and len(sys.argv) == 1:
     rng = np.random.default_rng(0)
     cases = [("C1 ne8 M5 n5", np.linspace(-1, 1, 9), 5, 1e4, 5),
              ("default ne24 M8 n12", np.linspace(-1, 1, 25), 8, 1e4, 12),
@@ -164,10 +164,15 @@ def gen_tables():
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gen"))
         import gen_cheb_tables as g
         Y, a, al, b, N = g.compute_tables()
+        X = g.compute_inverse(Y)
         f = lambda m: np.array([[float(x) for x in r] for r in m])
         _gen = (f(Y), np.array([float(x) for x in a]), np.array([float(x) for x in al]),
                 np.array([float(x) for x in b]), f(N))
+        global _genX
+        _genX = f(X)
     return _gen
+
+_genX = None
 
 def solve_cheb_kernel(s):
     Y, a, al, bb, N = gen_tables()
@@ -232,3 +237,101 @@ def solve_cheb_kernel(s):
     w[0] = d0 - C0 @ v
     w[1] = d1 - C1 @ v
     return w
+
+
+# ---------------------------------------------------------------------------------------------
+# RIDGE-DOMINATED elements (gamma scl^4 below ridge_gamma_scl4(M), round 4): the kernels' cold path
+# (enhance_small_cheb.hpp::cheb_ridge_solve, enhance_large_cheb.hip::ridge_wave_solve).  Same moments,
+# mapped back to the Legendre-bubble basis with the exact table X = Y^-1 (rho_j = sum_i X[i][j] T_i):
+#     S2_v = X^T (m_{i+k} + m_{|i-k|}) X + eps2 (I + C^T C),   rhs2_v = X^T r2 + eps2 C^T d,
+# exact boundary rows (Legendre recurrence).  In the Chebyshev basis the ridge is eps (N + C_z^T C_z),
+# N = Y^T Y, and once eps outweighs the Gram the solve inherits cond(Y)^2.
+# ---------------------------------------------------------------------------------------------
+def ridge_gamma_scl4(M):
+    """lssvr_device.hpp::ridge_gamma_scl4"""
+    return 3.0e-4 if M <= 12 else (1.0e-4 if M <= 17 else 3.0e-5)
+
+
+def solve_ridge_kernel(s):
+    gen_tables()
+    M, n = s.M, s.n
+    MR = M - 2
+    X = _genX[:MR, :MR]
+    t = s.t
+    hh = 0.5 * (s.b - s.a)
+    inv_scl2 = hh * hh
+    eps2 = 2.0 * inv_scl2 * inv_scl2 * (1.0 / s.gamma)
+    ta = s.off + s.scl * s.a
+    tb = s.off + s.scl * s.b
+    idet = 1.0 / (tb - ta)
+    gl, gr = s.g
+    d0 = (tb * gl - ta * gr) * idet
+    d1 = (gr - gl) * idet
+    if MR == 0:
+        return np.array([d0, d1])
+    La = np.zeros(M); Lb = np.zeros(M); La[0] = Lb[0] = 1.0; La[1] = ta; Lb[1] = tb
+    for p in range(1, M - 1):
+        La[p + 1] = ((2 * p + 1) * ta * La[p] - p * La[p - 1]) / (p + 1)
+        Lb[p + 1] = ((2 * p + 1) * tb * Lb[p] - p * Lb[p - 1]) / (p + 1)
+    C0 = (tb * La[2:] - ta * Lb[2:]) * idet
+    C1 = (Lb[2:] - La[2:]) * idet
+    phi2 = -2.0 * (s.f * inv_scl2)
+    T = np.zeros((n, MR)); T[:, 0] = 1.0
+    if MR > 1: T[:, 1] = t
+    for d in range(2, MR):
+        T[:, d] = (t + t) * T[:, d - 1] - T[:, d - 2]
+    m = T.sum(0); m[0] = n
+    P = (T[:, MR - 1:MR] * T).sum(0)
+    r = (T * phi2[:, None]).sum(0)
+    Mom = np.zeros(2 * MR - 1)
+    Mom[:MR] = m
+    for j in range(1, MR):
+        Mom[MR - 1 + j] = 2.0 * P[j] - m[MR - 1 - j]
+    G2 = np.array([[Mom[i + k] + Mom[abs(i - k)] for k in range(MR)] for i in range(MR)])
+    S = X.T @ (G2 @ X) + eps2 * (np.eye(MR) + np.outer(C0, C0) + np.outer(C1, C1))
+    rhs = X.T @ r + eps2 * (C0 * d0 + C1 * d1)
+    A = S.copy()
+    L = np.eye(MR); dd = np.zeros(MR)
+    for j in range(MR):
+        dd[j] = A[j, j]
+        L[j + 1:, j] = A[j + 1:, j] / dd[j]
+        A[j + 1:, j + 1:] -= np.outer(L[j + 1:, j], A[j, j + 1:])
+    y = np.linalg.solve(L, rhs); v = np.linalg.solve(L.T, y / dd)
+    w = np.zeros(M)
+    w[2:] = v
+    w[0] = d0 - C0 @ v
+    w[1] = d1 - C1 @ v
+    return w
+
+
+def solve_kernel_dispatch(s):
+    """What the Poisson kernels do per element: the ridge form below the threshold, else the moment form."""
+    if s.M > 2 and s.gamma_t < ridge_gamma_scl4(s.M):
+        return solve_ridge_kernel(s)
+    return solve_cheb_kernel(s)
+
+
+def ridge_sweep(seed=5, reps=3):
+    """Both forms against the 60-digit minimiser across gamma scl^4 (smooth: h = 0.5; rough: h = 100, fifty
+    periods of the right-hand side per element): where the threshold of ridge_gamma_scl4 comes from."""
+    rng = np.random.default_rng(seed)
+    print("M  n   h     g*scl^4 | direct Gram | moment form | ridge form | dispatch      (coef / bubble)")
+    for (M, n) in [(5, 5), (9, 16), (14, 28), (22, 44), (33, 64)]:
+        for h in [0.5, 100.0]:
+            for g4 in [1e-12, 1e-9, 1e-6, 1e-5, 3e-5, 1e-4, 3e-4, 1e-3, 1e-2, 1.0, 1e4]:
+                gamma = g4 / (2.0 / h) ** 4
+                worst = np.zeros((4, 2))
+                for _ in range(reps):
+                    x0 = rng.uniform(-30, 30) * h
+                    s = orc.element_system(x0, x0 + h, rng.normal(), rng.normal(), M, gamma, n)
+                    tr = cf.solve_truth(s)
+                    for i, f in enumerate([orc.solve_bc_eliminated, solve_cheb_kernel, solve_ridge_kernel,
+                                           solve_kernel_dispatch]):
+                        w = f(s)
+                        worst[i] = np.maximum(worst[i], [orc.rel_l2_coef(w[None], tr[None])[0],
+                                                         orc.rel_l2_bubble(w[None], tr[None])[0]])
+                print(f"{M:2d} {n:2d} {h:6.1f} {g4:8.0e} | " + " | ".join(f"{w[0]:.1e}/{w[1]:.1e}" for w in worst))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "ridge":
+    ridge_sweep()

@@ -476,27 +476,152 @@ def test_lane_kernel_exact_boundary_rows_cold_path(dev, note, M, ratio):
         assert err <= 2e-15, err                # measured 1.1e-16 .. 2.3e-16
 
 
-def test_lane_kernel_cold_path_is_per_wave(dev):
+@pytest.mark.parametrize("h_right", [8.0, 4000.0])
+def test_lane_kernel_cold_path_is_per_wave(dev, note, h_right):
     """One mesh, far from the origin on the left and near it on the right: some waves take the
     exact boundary rows, others the first-order ones; both agree with the oracle and the switch
-    leaves no seam."""
+    leaves no seam.  h_right = 8: gamma scl^4 = 39, the moment form; h_right = 4000 (round 3's first
+    contact, gpurun_out/pytest_r3a.log: 7.6e-13 against the 60-digit minimiser): gamma scl^4 = 6e-10,
+    RIDGE-DOMINATED -- those waves solve in the Legendre-bubble basis (cheb_ridge_solve, round 4)."""
     M, n = 9, 16
-    left = 3.0e7 + 0.05 * np.arange(200)                       # |x|/h = 6e8: cold
-    right = left[-1] + np.cumsum(np.full(250, 8.0))            # |x|/h = 4e6: first order (gamma scl^4 = 39)
+    left = 3.0e7 + 0.05 * np.arange(200)                       # |x|/h = 6e8: cold boundary rows
+    right = left[-1] + np.cumsum(np.full(250, h_right))        # |x|/h = 4e6 (7.5e3): first-order rows
     nodes = np.concatenate([left, right])
     ne = len(nodes) - 1
     values = np.cos(0.37 * np.arange(ne + 1))
     gd = (nodes[0], nodes[-1])
     _, slow_wave = _boundary_rows_slow(nodes, M)
     assert slow_wave[:3].all() and not slow_wave[4:].any()
+    ridge = _ridge_dominated(nodes, M, 1e4)
+    assert not ridge[:199].any() and ridge[199:].all() == (h_right > 100.0) and ridge[199:].any() == (h_right > 100.0)
     W, st = _enhance(dev, nodes, values, M, 1e4, n, global_domain=gd)
     assert np.all(st == 0)
     Wo = orc.enhance_all_vec(nodes, values, M, 1e4, n, global_domain=gd)
     assert orc.rel_l2_coef(W, Wo).max() <= 1e-11
     if cf.HAVE_MP:
-        sel = [0, 191, 192, 199, 200, 255, 256, ne - 1]
+        sel = [0, 191, 192, 198, 199, 200, 255, 256, ne - 1]   # 198 / 199: the last fine, the first coarse element
         tr = cf.truth_all(nodes, values, M, 1e4, n, orc.poisson_rhs, gd, sel)
-        assert orc.rel_l2_coef(W[sel], tr).max() <= TOL_TRUTH
+        err = orc.rel_l2_coef(W[sel], tr).max()
+        note("cold path per wave, h_right=%g vs 60-digit minimiser" % h_right, err, TOL_TRUTH)
+        assert err <= TOL_TRUTH, err
+
+
+def _ridge_dominated(nodes, M, gamma):
+    """The kernels' predicate (lssvr_device.hpp::ridge_dominated), restated: gamma scl^4 below
+    ridge_gamma_scl4(M) -- the element is solved in the Legendre-bubble basis."""
+    h = np.diff(nodes)
+    thr = 3.0e-4 if M <= 12 else (1.0e-4 if M <= 17 else 3.0e-5)
+    g4 = np.asarray(gamma, dtype=np.float64) * (2.0 / h) ** 4
+    return (M > 2) & (g4 < thr)
+
+
+# gamma scl^4 of the sweep x (M, n): the verdict's table of round 3 (Chebyshev-moment form 2.6e-13 at M = 9 ..
+# 3e-11 at M = 22 / 33 where the float64 KKT solve holds 1e-15) and its two decades towards the crossover.
+RIDGE_SWEEP = [(M, n, g4) for (M, n) in [(5, 5), (9, 16), (14, 28), (22, 44), (33, 64)]
+               for g4 in (1e-3, 1e-6, 1e-9, 1e-12)]
+
+
+@pytest.mark.skipif(not cf.HAVE_MP, reason="mpmath missing")
+@pytest.mark.parametrize("M,n,g4", RIDGE_SWEEP)
+def test_ridge_dominated_sweep(dev, note, M, n, g4):
+    """gamma scl^4 << 1 (coarse elements with a small penalty): in the Chebyshev basis the ridge is
+    eps (N + C_z^T C_z), N = Y^T Y, and the moment form inherits cond(Y)^2 (round 3: 2.6e-13 at M = 9,
+    3e-11 at M = 22 and 33, against 1e-15 of a float64 KKT solve).  Round 4: below
+    ridge_gamma_scl4(M) the kernels solve in the Legendre-bubble basis from the same moments
+    (cheb_ridge_solve per lane, ridge_wave_solve per wave above M = 22).  Every entry -- in-kernel and
+    tabulated right-hand side (both layouts), the fused step, a subset launch -- against the 60-digit
+    minimiser of the reference's QP (Dual.py:46-78) at 1e-13; at M = 33 the problem's own conditioning
+    shows at gamma scl^4 = 1e-6 (float64 KKT / direct Gram: 4e-13 .. 6e-13 on this mesh): the bar there
+    is 4 x the float64 oracle's own error, and never below 1e-13."""
+    import torch
+    from hybrid_fem_lssvr_amd import ops
+    ne, h = 150, 0.5                            # three waves, the last one partial
+    gamma = g4 / (2.0 / h) ** 4
+    rng = np.random.default_rng(M * 1000 + n)
+    nodes = -1.0 + h * np.arange(ne + 1)
+    values = np.sin(np.pi * nodes) + 0.01 * rng.standard_normal(ne + 1)
+    gd = (nodes[0], nodes[-1])
+    ridge = _ridge_dominated(nodes, M, gamma)
+    assert ridge.all() == (g4 < 1e-4) and ridge.any() == (g4 < 1e-4)      # 1e-3: the moment form, below: the ridge form
+    x, u = _t(nodes, dev), _t(values, dev)
+    sel = [0, 1, 63, 64, 127, 128, ne - 1]
+    tr = cf.truth_all(nodes, values, M, gamma, n, orc.poisson_rhs, gd, sel)
+    W, st = ops.enhance(x, u, M, gamma, n, global_domain=gd)
+    xc = ops.colloc_points(x, n)
+    f = _t(orc.poisson_rhs(xc.cpu().numpy()), dev)
+    W2, st2 = ops.enhance(x, u, M, gamma, n, global_domain=gd, rhs_values=f)
+    W3, _ = ops.enhance(x, u, M, gamma, n, global_domain=gd, rhs_values=f.t().contiguous(), point_major=True)
+    plan = ops.StepPlan(x, u, M, gamma, n, global_domain=gd)
+    W4, st4 = plan.launch()
+    W5 = torch.zeros((ne, M + 3), dtype=torch.float64, device=dev)
+    st5 = torch.full((ne,), -7, dtype=torch.int32, device=dev)
+    ops.enhance_subset(x, u, M, gamma, n, W5, elem_ids=_t(np.array(sel, dtype=np.int64), dev), global_domain=gd,
+                       status=st5)
+    torch.cuda.synchronize()
+    assert int(st.sum()) == 0 and int(st2.sum()) == 0 and int(st4.sum()) == 0
+    st5 = st5.cpu().numpy()
+    assert np.all(st5[sel] == 0) and np.all(np.delete(st5, sel) == -7)
+    W5 = W5.cpu().numpy()
+    assert np.all(W5[:, M:] == 0.0) and np.all(np.delete(W5, sel, axis=0) == 0.0)
+    bar = TOL_TRUTH
+    oracle_err = max(orc.rel_l2_coef(orc.enhance_all_vec(nodes, values, M, gamma, n, global_domain=gd)[sel], tr).max(),
+                     max(orc.rel_l2_coef(orc.solve_primal_kkt(orc.element_system(
+                         nodes[i], nodes[i + 1], *orc.boundary_values(i, ne, nodes[i], nodes[i + 1], values[i],
+                                                                      values[i + 1], gd), M, gamma, n))[None],
+                                         tr[k][None])[0] for k, i in enumerate(sel)))
+    if M == 33:
+        bar = max(bar, 4.0 * oracle_err)
+    worst = 0.0
+    for Wx in (W.cpu().numpy(), W2.cpu().numpy(), W3.cpu().numpy(), W4.cpu().numpy(), W5[:, :M]):
+        worst = max(worst, orc.rel_l2_coef(Wx[sel], tr).max(), orc.rel_l2_bubble(Wx[sel], tr).max())
+    note("ridge sweep M=%d n=%d gamma scl^4=%.0e vs 60-digit minimiser (float64 oracle: %.1e)" % (M, n, g4, oracle_err),
+         worst, bar)
+    assert worst <= bar, (worst, bar, oracle_err)
+    assert torch.equal(W, W4)
+
+
+@pytest.mark.skipif(not cf.HAVE_MP, reason="mpmath missing")
+@pytest.mark.parametrize("M,n", [(9, 16), (20, 18), (33, 64), (33, 40)])
+def test_ridge_dominated_lanes_inside_a_wave(dev, note, M, n):
+    """Ridge-dominated and ordinary elements side by side in one wave (alternating element lengths and a
+    per-element gamma through the subset entry): a ridge lane takes the Legendre-bubble solve, its
+    neighbours keep the moment form -- including the near-square refinement at (20, 18) and (33, 40) --
+    and the two-kernel path's solve kernels leave the rows moments_kernel wrote alone."""
+    import torch
+    from hybrid_fem_lssvr_amd import ops
+    ne = 200
+    rng = np.random.default_rng(M + n)
+    coarse = np.arange(ne) % 3 == 0
+    hs = np.where(coarse, 40.0, 0.25)                          # scl^4 = 6e-6 / 4096
+    nodes = np.concatenate([[-3.0], -3.0 + np.cumsum(hs)])
+    values = 0.3 * rng.standard_normal(ne + 1)
+    gd = (nodes[0], nodes[-1])
+    gam = np.where(coarse, 1e-5, 1e3) * 10.0 ** rng.uniform(-1, 1, ne)   # gamma scl^4 ~ 6e-11 / 4e6
+    gam[5::7] = 1e-14                                           # a few fine elements ridge-dominated through gamma
+    ridge = _ridge_dominated(nodes, M, gam)
+    assert ridge[:64].any() and not ridge[:64].all() and ridge[0] and not ridge[1] and ridge[5]
+    x, u = _t(nodes, dev), _t(values, dev)
+    W = torch.zeros((ne, M), dtype=torch.float64, device=dev)
+    st = torch.full((ne,), -7, dtype=torch.int32, device=dev)
+    fc = torch.zeros(1, dtype=torch.int32, device=dev)
+    ops.enhance_subset(x, u, M, 1.0, n, W, gamma_values=_t(gam, dev), global_domain=gd, status=st, fail_count=fc)
+    torch.cuda.synchronize()
+    assert int(fc.item()) == 0 and int(st.abs().sum()) == 0
+    W = W.cpu().numpy()
+    sel = [0, 1, 2, 3, 5, 6, 63, 64, 65, 66, ne - 2, ne - 1]
+    worst_r, worst_o = 0.0, 0.0
+    for i in sel:
+        gl, gr = orc.boundary_values(i, ne, nodes[i], nodes[i + 1], values[i], values[i + 1], gd)
+        s = orc.element_system(nodes[i], nodes[i + 1], gl, gr, M, gam[i], n)
+        tr = cf.solve_truth(s)
+        e = float(orc.rel_l2_coef(W[i][None], tr[None])[0])
+        if ridge[i]:
+            worst_r = max(worst_r, e)
+        else:
+            worst_o = max(worst_o, e)
+    note("mixed wave M=%d n=%d: ridge lanes vs 60-digit minimiser" % (M, n), worst_r, TOL_TRUTH)
+    note("mixed wave M=%d n=%d: ordinary lanes vs 60-digit minimiser" % (M, n), worst_o, TOL_TRUTH)
+    assert worst_r <= TOL_TRUTH and worst_o <= TOL_TRUTH, (worst_r, worst_o)
 
 
 @pytest.mark.parametrize("x0,h", [(1.0e9, 512.0), (-3.0e8, 1.0 / 12), (2.5e9, 0.7)])
@@ -594,8 +719,13 @@ def test_random_parity_sweep(dev, note, seed):
     the default solver can take (lane kernel incl. its cold paths and near-square refinement, moment /
     parity-split / refined two-kernel path, dual solver below the rank boundary), each against the
     60-digit minimiser of the reference's QP (Dual.py:46-78) at the same float64 abscissae.
-    Bar: 1e-13 where gamma scl^4 >= 1 and h <= 1 (every regime a mesh refinement produces); coarse
-    elements with a tiny penalty are the problem's own cond(A) u (round 2's sweep: worst 2e-12): 5e-12."""
+    Bar: 1e-13 where gamma scl^4 >= 1 and h <= 1 (every regime a mesh refinement produces) AND where the
+    ridge dominates outright (gamma scl^4 <= 1e-8: round 3's docstring called that regime "the problem's
+    own cond(A) u" -- it was the moment form's cond(Y)^2, a float64 KKT solve holds 1e-15 there; since
+    round 4 those elements are solved in the Legendre-bubble basis).  In between (1e-8 < gamma scl^4 < 1,
+    or elements many periods of the right-hand side long) the high-degree directions are Gram-dominated
+    and the low ones ridge-dominated: there the float64 KKT solve itself reads 1e-13 .. 1e-11 at
+    M >= 22 (scripts/proto/cheb_moment.py ridge): 1e-12 (measured over the three seeds: 1.4e-14)."""
     import torch
     from hybrid_fem_lssvr_amd import ops
     rng = np.random.default_rng(seed)
@@ -621,12 +751,14 @@ def test_random_parity_sweep(dev, note, seed):
         assert np.all(st[sel] == 0), (M, n, gamma, h, x0)
         tr = cf.truth_all(nodes, values, M, gamma, n, orc.poisson_rhs, gd, sel)
         err = float(orc.rel_l2_coef(W[sel], tr).max())
-        well_posed = gamma * (2.0 / np.diff(nodes).max()) ** 4 >= 1.0 and np.diff(nodes).max() <= 1.0
-        if well_posed:
+        hd = np.diff(nodes)
+        well_posed = gamma * (2.0 / hd.max()) ** 4 >= 1.0 and hd.max() <= 1.0
+        ridge_only = gamma * (2.0 / hd.min()) ** 4 <= 1.0e-8
+        if well_posed or ridge_only:
             worst_tight = max(worst_tight, err)
             assert err <= 1e-13, (err, M, n, gamma, h, x0)
         else:
             worst_loose = max(worst_loose, err)
-            assert err <= 5e-12, (err, M, n, gamma, h, x0)
-    note("random sweep seed %d: worst, well-posed regime" % seed, worst_tight, 1e-13)
-    note("random sweep seed %d: worst, coarse / tiny-penalty regime" % seed, worst_loose, 5e-12)
+            assert err <= 1e-12, (err, M, n, gamma, h, x0)
+    note("random sweep seed %d: worst, well-posed or ridge-dominated regime" % seed, worst_tight, 1e-13)
+    note("random sweep seed %d: worst, mixed regime (1e-8 < gamma scl^4 < 1 or h > 1)" % seed, worst_loose, 1e-12)
