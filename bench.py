@@ -157,42 +157,70 @@ def _cpu_worker(args):
     os.environ["OMP_NUM_THREADS"] = os.environ["OPENBLAS_NUM_THREADS"] = "1"
     import numpy as np
     from oracle import lssvr_oracle as orc
-    nodes, values, elems, ne, gd, seed, varcoef = args
+    nodes, values, j, ne, gd, seed, varcoef, M, n = args
     rng = np.random.default_rng(seed)
     rhs, kw = orc.poisson_rhs, {}
     if varcoef:
         a, da, f = orc.varcoef_functions(*orc.varcoef_params())
         rhs, kw = f, {"coef_a": a, "coef_da": da}
     t0 = time.perf_counter()
-    ok = 0
-    for i in elems:
-        j = int(i)
-        _, s = orc.slsqp_element(rhs, nodes[j], nodes[j + 1], values[j], values[j + 1],
-                                 M_DEG8, GAMMA, N_COLLOC, left=(j == 0), right=(j == ne - 1),
-                                 global_domain=gd, rng=rng, **kw)
-        ok += int(s)
-    return len(elems), ok, time.perf_counter() - t0
+    _, ok = orc.slsqp_element(rhs, nodes[j], nodes[j + 1], values[j], values[j + 1],
+                              M, GAMMA, n, left=(j == 0), right=(j == ne - 1),
+                              global_domain=gd, rng=rng, **kw)
+    return int(ok), time.perf_counter() - t0
 
 
-def cpu_baseline(nodes_host, values_host, gd, per_core=16, varcoef=False):
+def wide_mesh(ne):
+    """Host nodes / nodal values of the reference-valid synthetic mesh: h = 1/12 on [-ne/24, ne/24]
+    (SURVEY.md 8(d) S-wide), u_i = sin(pi x_i) with the Dirichlet ends."""
+    import numpy as np
+    half = ne / 24.0
+    nodes = np.arange(ne + 1, dtype=np.float64) * ((2.0 * half) / ne) - half
+    nodes[-1] = half
+    values = np.sin(np.pi * nodes)
+    values[0] = values[-1] = 0.0
+    return nodes, values, (-half, half)
+
+
+def cpu_baseline(nodes_host, values_host, gd, per_core=16, varcoef=False, M=M_DEG8, n=N_COLLOC, note="",
+                 central=False, budget_s=45.0):
     """Times the SLSQP loop on a bounded sample of the same mesh with every host core the
-    box gives us (one process per core, like N copies of the single-threaded reference).
-    ``varcoef``: the residual of BASELINE config 5 (an extension of Dual.py:43-44)."""
+    box gives us (one process per core, like N copies of the single-threaded reference; one
+    element per job).  ``varcoef``: the residual of BASELINE config 5 (an extension of Dual.py:43-44).
+    ``central``: the sample is the elements nearest the origin of the mesh instead of an even spread -- degree
+    32 / 64 points: far from the origin (|x|/h = 5e4) single elements run into SLSQP's iteration limit after
+    ~200 s, near it every one converges in ~8-15 s (7.9 s).  ``budget_s``: jobs still running
+    after that long are abandoned and NOT counted (the rate is finished elements / wall time)."""
     import multiprocessing as mp
     import numpy as np
     cores = max(1, min(len(os.sched_getaffinity(0)), 16))
     ne = len(nodes_host) - 1
-    sample = np.linspace(0, ne - 1, cores * per_core).astype(np.int64)
-    parts = np.array_split(sample, cores)
-    jobs = [(nodes_host, values_host, p, ne, gd, 1000 + k, varcoef) for k, p in enumerate(parts)]
+    count = min(ne, cores * per_core)
+    if central:
+        sample = np.arange(ne // 2 - count // 2, ne // 2 - count // 2 + count, dtype=np.int64)
+    else:
+        sample = np.linspace(0, ne - 1, count).astype(np.int64)
+    jobs = [(nodes_host, values_host, int(j), ne, gd, 1000 + k, varcoef, M, n) for k, j in enumerate(sample)]
     ctx = mp.get_context("fork")
     t0 = time.perf_counter()
-    with ctx.Pool(cores) as pool:
-        res = pool.map(_cpu_worker, jobs)
+    res, abandoned = [], 0
+    pool = ctx.Pool(cores)
+    try:
+        it = pool.imap_unordered(_cpu_worker, jobs)
+        for _ in jobs:
+            left = budget_s - (time.perf_counter() - t0)
+            try:
+                res.append(it.next(timeout=max(left, 0.01)))
+            except mp.TimeoutError:
+                abandoned = len(jobs) - len(res)
+                break
+    finally:
+        pool.terminate()
+        pool.join()
     wall = time.perf_counter() - t0
-    done = sum(r[0] for r in res)
-    conv = sum(r[1] for r in res)
-    busy = sum(r[2] for r in res)
+    done = len(res)
+    conv = sum(r[0] for r in res)
+    busy = sum(r[1] for r in res)
     model = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -201,18 +229,21 @@ def cpu_baseline(nodes_host, values_host, gd, per_core=16, varcoef=False):
                 break
     except OSError:
         pass
+    where = ("the %d elements nearest the origin of" % count) if central else ("%d elements evenly spaced through" % count)
     return {
         "value": done / wall,
         "unit": "elements/s",
         "cores": cores,
         "cpu_model": model,
         "kind": "port",
-        "sample": f"{done} elements evenly spaced through the same {ne}-element mesh, "
+        "sample": f"{where} the same {ne}-element mesh, degree {M - 1} / {n} points, "
                   f"per-element scipy SLSQP loop (oracle/lssvr_oracle.py::slsqp_element = "
                   f"Dual.py:20-98" + (" with the variable-coefficient residual -a u'' - a' u' - f, an "
                                       "extension of Dual.py:43-44" if varcoef else "")
-                  + f"), one process per core; {conv}/{done} converged",
-        "single_core_value": done / busy,
+                  + f"), one process per core; {done} finished, {conv} converged"
+                  + (f", {abandoned} abandoned at the {budget_s:.0f} s budget (not counted)" if abandoned else "") + note,
+        "single_core_value": (done / busy) if busy > 0 else None,
+        "wall_s": wall,
     }
 
 
@@ -323,16 +354,28 @@ def prewarm(launch, st):
     return pre + 9
 
 
-def timed_compute(wl, D, steps, warmup, mode=None):
-    """K steps of the fused step on the current stream between two HIP events; barrier + device
+REPLAYS = max(1, int(os.environ.get("LSSVR_BENCH_REPLAYS", "11")))
+
+
+class Timed(dict):
+    """Result of timed_compute: seconds per bracket of K steps -- ``s`` the median over the brackets (what
+    ``value`` divides by), ``s_min`` / ``s_max``, ``brackets``, ``wall_s`` (host clock around the median's
+    neighbourhood: the mean host time per bracket), ``mode``."""
+    __getattr__ = dict.__getitem__
+
+
+def timed_compute(wl, D, steps, warmup, mode=None, replays=None):
+    """EXACTLY K steps of the fused step on the current stream between two HIP events, barrier + device
     synchronisation on both sides, nothing but the launches (mode "eager") or the replay of the K captured
-    launches (mode "graph", see TIMED_MODE) inside.  Returns (max over ranks of the device time [s], max over
-    ranks of the host wall time [s]); the mode really used is appended to TIMED_USED."""
+    launches (mode "graph", see TIMED_MODE) inside -- and that bracket ``replays`` times (the
+    median of >= 10 timed repetitions; min and max are reported beside it).  Every bracket is reduced to the
+    maximum over ranks AFTER its region.  The mode really used is appended to TIMED_USED."""
     import torch
     from hybrid_fem_lssvr_amd import ops
     st = torch.cuda.current_stream().cuda_stream
     plan = wl.plans[0]
     mode = mode or TIMED_MODE
+    replays = replays or REPLAYS
     prewarm(plan.launch, st)
     for _ in range(warmup):
         plan.launch(st)
@@ -348,22 +391,42 @@ def timed_compute(wl, D, steps, warmup, mode=None):
             graph, used = None, "eager (hipGraph capture failed: %r)" % (exc,)
     TIMED_USED.append(used)
     D.barrier()
-    D.barrier()
-    e0 = torch.cuda.Event(enable_timing=True)
-    e1 = torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record()
-    if graph is not None:
-        graph.replay()
-    else:
-        for _ in range(steps):
-            plan.launch(st)
-    e1.record()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    D.barrier()
-    dev_s = e0.elapsed_time(e1) * 1e-3
-    return D.max(dev_s), D.max(wall)
+    dev, wall = [], []
+    for _ in range(replays):
+        D.barrier()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        if graph is not None:
+            graph.replay()
+        else:
+            for _ in range(steps):
+                plan.launch(st)
+        e1.record()
+        torch.cuda.synchronize()
+        wall.append(time.perf_counter() - t0)
+        D.barrier()
+        dev.append(e0.elapsed_time(e1) * 1e-3)
+    dev = [D.max(v) for v in dev]
+    srt = sorted(dev)
+    return Timed(s=srt[len(srt) // 2], s_min=srt[0], s_max=srt[-1], brackets=len(srt),
+                 wall_s=D.max(sum(wall) / len(wall)), mode=used)
+
+
+def timing_fields(t, steps, ne_total):
+    """The contract's value / ms_per_step (median bracket) with the spread beside them."""
+    return {"value": ne_total * steps / t.s, "ms_per_step": t.s / steps * 1e3,
+            "timed_brackets": t.brackets,
+            "ms_per_step_min": t.s_min / steps * 1e3, "ms_per_step_max": t.s_max / steps * 1e3,
+            "value_is": "elements of the K steps / the MEDIAN of %d event-bracketed repetitions of exactly K steps "
+                        "(barrier + device synchronisation on both sides of every one; SURVEY.md 8(d))" % t.brackets,
+            "host_wall_ms_per_step": t.wall_s / steps * 1e3}
+
+
+def region_text(used):
+    return ("the K steps captured once in a hipGraph (untimed, like the warm-up) and replayed"
+            if used.startswith("graph") else "K launches issued call by call: " + used)
 
 
 def timed_stitch(wl, D, steps, warmup, what, algo, samples=SAMPLES_PER_ELEMENT):
@@ -446,13 +509,11 @@ def measure_multi(wl, D, steps, warmup, algos, samples_list=(2, 1)):
     ``samples_list`` (the first one is the headline ``stitch_u``), then W.  A failure inside a timed
     collective region is NOT caught per rank (the others would block in the collective): it ends the
     job, and bench.py's self-launcher / torchrun ends the sibling ranks."""
-    dev_s, wall_s = timed_compute(wl, D, steps, warmup)
+    t = timed_compute(wl, D, steps, warmup)
     total = wl.ne_glob * steps
     res = {"elements_total": wl.ne_glob, "elements_per_rank": wl.plan.max_size,
-           "value": total / dev_s, "ms_per_step": dev_s / steps * 1e3,
-           "host_wall_ms_per_step": wall_s / steps * 1e3,
-           "timed_region": ("the K steps captured once in a hipGraph per rank (untimed, like the warm-up) and replayed"
-                            if TIMED_USED[-1].startswith("graph") else "K launches issued call by call: " + TIMED_USED[-1])}
+           **timing_fields(t, steps, wl.ne_glob), "step_s": t.s / steps,
+           "timed_region": region_text(t.mode) + " (one graph per rank)"}
     jobs = [("u", sp) for sp in samples_list] + [("W", None)]
     for what, sp in jobs:
         by_algo = {}
@@ -494,7 +555,7 @@ def main():
                     help="dual: time LSSVR_SOLVER_DUAL (north_star's Gram form) instead of the default solver")
     ap.add_argument("--config", type=int, choices=[2, 4, 5], default=2,
                     help="BASELINE config: 2 = degree 8 / 16 points (default; the flags above refine it), "
-                         "4 = degree 32 / 64 points on 1e5 elements of [-1,1], 5 = variable coefficient "
+                         "4 = degree 32 / 64 points on 100 008 elements (h = 1/12; --domain narrow: 1e5 on [-1,1]), 5 = variable coefficient "
                          "-(a u')' = f, 1e6 elements, degree 8 / 16 points, tabulated a, a', f")
     ap.add_argument("--table-layout", choices=["point", "element"], default="point",
                     help="--config 5: layout of the tabulated a, a', f (point-major t[k, e] is what the lane kernel "
@@ -503,6 +564,8 @@ def main():
                     help="N > 1: points per element of the stitched u (0 = report both 1 and 2; value_with_allgather "
                          "is the 2-point line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-embedded", action="store_true",
+                    help="default N = 1 run: skip the compact config 4 / config 5 lines it carries")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the stitch measurements")
     ap.add_argument("--no-second-line", action="store_true", help="N > 1: skip the other scaling mode")
     args = ap.parse_args()
@@ -533,8 +596,7 @@ def main():
     import numpy as np
 
     if args.config == 4:
-        args.degree, args.colloc, args.domain = 32, 64, "narrow"
-        args.elements = args.elements or NE_NARROW
+        args.degree, args.colloc = 32, 64
     if args.config == 5:
         args.degree, args.colloc = 8, N_COLLOC
     M = args.degree + 1
@@ -556,20 +618,39 @@ def main():
         lo, hi = -half, half
     else:
         lo, hi = -1.0, 1.0
+    # the default N = 1 run also carries compact lines of BASELINE configs 4 and 5 (`config4`, `config5`), so that
+    # one driver run on a fresh box times all three
+    embed = (not multi and args.config == 2 and args.degree == 8 and n == N_COLLOC and args.domain == "wide"
+             and not args.elements and args.solver == "primal" and not args.no_embedded)
 
-    # CPU baseline first (N = 1 only): its worker processes are forked before this process
-    # touches the GPU (a forked child of a GPU-initialised process is best avoided on this pool)
-    cpu_res = None
-    # (wide domain only: on [-1, 1] the SLSQP loop stops converging above ~5e4 elements, SURVEY.md finding 5)
-    if (not multi and not args.no_cpu_baseline and M == M_DEG8 and n == N_COLLOC and args.solver == "primal"
-            and args.domain == "wide"):
-        step_h = (hi - lo) / ne_glob
-        nodes_h = np.arange(ne_glob + 1, dtype=np.float64) * step_h + lo
-        nodes_h[-1] = hi
-        values_h = np.sin(np.pi * nodes_h)
-        values_h[0] = values_h[-1] = 0.0
-        cpu_res = cpu_baseline(nodes_h, values_h, (lo, hi), varcoef=(args.config == 5),
-                               per_core=(8 if args.config == 5 else 16))
+    # CPU baselines first: the worker processes are forked before this process touches the GPU (a forked child
+    # of a GPU-initialised process is best avoided on this pool).  Rank 0 only; wide domain only (on [-1, 1] the
+    # SLSQP loop stops converging above ~5e4 elements, SURVEY.md finding 5: for a narrow-domain line the sample
+    # is taken from the h = 1/12 mesh of the same element count, and says so).
+    cpu_res, cpu4, cpu5 = None, None, None
+    if rank == 0 and not args.no_cpu_baseline and args.solver == "primal" and M <= 33:
+        note = ""
+        if args.domain == "wide":
+            step_h = (hi - lo) / ne_glob
+            nodes_h = np.arange(ne_glob + 1, dtype=np.float64) * step_h + lo
+            nodes_h[-1] = hi
+            values_h = np.sin(np.pi * nodes_h)
+            values_h[0] = values_h[-1] = 0.0
+            gd_h = (lo, hi)
+        else:
+            nodes_h, values_h, gd_h = wide_mesh(ne_glob + (-ne_glob) % 24)
+            note = ("; sampled from the h = 1/12 mesh of (nearly) the same element count: on [-1, 1] the reference's "
+                    "SLSQP stops converging above ~5e4 elements (SURVEY.md finding 5)")
+        # ~10-30 s of CPU work: 16 elements per core at degree 8 (0.2 s each), ONE per core at degree 32 (8 s each)
+        per_core = 1 if M > 22 else (8 if args.config == 5 else 16)
+        cpu_res = cpu_baseline(nodes_h, values_h, gd_h, varcoef=(args.config == 5), per_core=per_core, M=M, n=n,
+                               note=note, central=(M > 22))
+        if embed:
+            nd, vl, gd4 = wide_mesh(NE_WIDE)
+            cpu4 = cpu_baseline(nd, vl, gd4, per_core=1, M=33, n=64, central=True)
+            nd, vl, gd5 = wide_mesh(NE_C5_WIDE)
+            cpu5 = cpu_baseline(nd, vl, gd5, varcoef=True, per_core=8)
+            del nd, vl
 
     import torch
     import torch.distributed as dist
@@ -606,11 +687,42 @@ def main():
     D = Dist(use_dist, backend, dev)
 
     if multi:
-        out = run_multi(args, D, M, n, ne_glob, lo, hi, rank, world, dev, backend)
+        out = run_multi(args, D, M, n, ne_glob, lo, hi, rank, world, dev, backend, cpu_res)
     elif args.config == 5:
-        out = run_config5(args, D, M, n, ne_glob, lo, hi, dev, cpu_res)
+        out = measure_config5(D, M, n, ne_glob, lo, hi, dev, args.steps, args.warmup,
+                              pm=(args.table_layout == "point"), full=True, cpu_res=cpu_res,
+                              narrow_too=(args.domain == "wide" and not args.elements))
     else:
-        out = run_single(args, D, M, n, ne_glob, lo, hi, dev, cpu_res, use_dist)
+        default_run = args.domain == "wide" and not args.elements and args.solver == "primal"
+        label = ("; BASELINE config %d" % args.config) if default_run and (M, n) in ((9, 16), (33, 64)) else ""
+        out = measure_poisson(D, M, n, ne_glob, lo, hi, dev, args.steps, args.warmup, solver=args.solver, full=True,
+                              cpu_res=cpu_res, use_dist=use_dist, label=label)
+        if default_run:
+            # the same step on exactly 1e5 elements of [-1, 1] (BASELINE.json's wording), where the CPU baseline
+            # cannot be timed (SURVEY.md finding 5): shows that the kernel cost does not depend on the domain
+            try:
+                wn = Workload(NE_NARROW, -1.0, 1.0, M, n, 0, 1, dev)
+                tn = timed_compute(wn, D, args.steps, args.warmup, replays=5)
+                out["narrow_domain"] = {"workload": "%d elements on [-1, 1], same step" % NE_NARROW,
+                                        "value": NE_NARROW * args.steps / tn.s, "ms_per_step": tn.s / args.steps * 1e3,
+                                        "fallback_elements": int(wn.status.sum().item())}
+                del wn
+            except Exception as exc:  # pragma: no cover
+                out["narrow_domain"] = {"error": repr(exc)}
+        if embed:
+            torch.cuda.empty_cache()
+            for key, fn in (("config4", lambda: measure_poisson(D, 33, 64, NE_WIDE, -NE_WIDE / 24.0, NE_WIDE / 24.0, dev,
+                                                                 args.steps, min(args.warmup, 5), full=False,
+                                                                 cpu_res=cpu4, label="; BASELINE config 4")),
+                            ("config5", lambda: measure_config5(D, M_DEG8, N_COLLOC, NE_C5_WIDE, -NE_C5_WIDE / 24.0,
+                                                                 NE_C5_WIDE / 24.0, dev, args.steps,
+                                                                 min(args.warmup, 5), pm=True, full=False,
+                                                                 cpu_res=cpu5))):
+                try:
+                    out[key] = fn()
+                except Exception as exc:  # pragma: no cover
+                    out[key] = {"error": repr(exc)}
+                torch.cuda.empty_cache()
     if rank == 0:
         emit(json.dumps(out))
     if use_dist:
@@ -621,7 +733,7 @@ def main():
 # ----------------------------------------------------------------------------------------
 # N > 1
 # ----------------------------------------------------------------------------------------
-def run_multi(args, D, M, n, ne_glob, lo, hi, rank, world, dev, backend):
+def run_multi(args, D, M, n, ne_glob, lo, hi, rank, world, dev, backend, cpu_res=None):
     import torch
     import torch.distributed as dist
     from hybrid_fem_lssvr_amd.distributed import ALLGATHER_ALGOS
@@ -658,7 +770,7 @@ def run_multi(args, D, M, n, ne_glob, lo, hi, rank, world, dev, backend):
         try:
             if rank == 0:
                 w1 = Workload(ne_glob, lo, hi, M, n, 0, 1, dev)
-                d1, _ = timed_compute(w1, Dist(False, backend, dev), max(args.steps // 4, 3), 2)
+                d1 = timed_compute(w1, Dist(False, backend, dev), max(args.steps // 4, 3), 2, replays=3).s
                 one_rank = {"what": "the same %d elements on rank 0 alone, compute only" % ne_glob,
                             "value": ne_glob * max(args.steps // 4, 3) / d1,
                             "ms_per_step": d1 / max(args.steps // 4, 3) * 1e3}
@@ -673,7 +785,7 @@ def run_multi(args, D, M, n, ne_glob, lo, hi, rank, world, dev, backend):
         if rank == 0:
             wr = Workload(wl.plan.max_size, lo, lo + (hi - lo) * wl.plan.max_size / ne_glob, M, n, 0, 1, dev)
             k3 = max(args.steps // 2, 5)
-            dr, _ = timed_compute(wr, Dist(False, backend, dev), k3, 3)
+            dr = timed_compute(wr, Dist(False, backend, dev), k3, 3, replays=5).s
             per_rank = {"what": "%d elements (one rank's share) on rank 0 alone, compute only" % wl.plan.max_size,
                         "value": wl.plan.max_size * k3 / dr, "ms_per_step": dr / k3 * 1e3}
             del wr
@@ -702,6 +814,10 @@ def run_multi(args, D, M, n, ne_glob, lo, hi, rank, world, dev, backend):
         "warmup": args.warmup,
         "prewarm_steps": PREWARM_DONE,
         "ms_per_step": res["ms_per_step"],
+        "ms_per_step_min": res["ms_per_step_min"],
+        "ms_per_step_max": res["ms_per_step_max"],
+        "timed_brackets": res["timed_brackets"],
+        "value_is": res["value_is"],
         "ms_per_step_with_allgather": su.get("ms_per_step"),
         "host_wall_ms_per_step": res["host_wall_ms_per_step"],
         "higher_is_better": True,
@@ -723,6 +839,35 @@ def run_multi(args, D, M, n, ne_glob, lo, hi, rank, world, dev, backend):
         "stitch_u": res.get("stitch_u"),
         "stitch_W": res.get("stitch_W"),
     }
+    # AGGREGATE roofline of the compute-only region: every rank launches the same fused step on its shard; the
+    # region lasts as long as the slowest rank's K launches (max over ranks, taken after the region), so the job's
+    # achieved rate is the algorithmic work of ALL shards over that time, against N x the one-GPU peaks
+    flops, byts = algorithmic_flops(M, n), algorithmic_bytes(M)
+    step_kernel, _, pipe, _, count_key = poisson_labels(M, n, False)
+    ach = flops * ne_glob / res["step_s"] / 1e12
+    gbs = byts * ne_glob / res["step_s"] / 1e9
+    out["roofline"] = {
+        "bound": "fp64-valu", "pipe": pipe, "kernel": step_kernel + ", one per rank",
+        "achieved": ach, "peak": FP64_PEAK_TFLOPS * world, "unit": "TFLOP/s", "frac": ach / (FP64_PEAK_TFLOPS * world),
+        "peak_is": "%d GPUs x %.1f TFLOP/s" % (world, FP64_PEAK_TFLOPS),
+        "flops_per_element": flops, "elements_per_launch": wl.plan.max_size, "elements_per_step_all_ranks": ne_glob,
+        "kernel_us_avg": res["step_s"] * 1e6,
+        "kernel_us_is": "launch-to-launch duration of the step's kernel(s) inside the timed region on the SLOWEST rank "
+                        "(median bracket / K, max over ranks per bracket)",
+        "achieved_is": "direct-Gram-EQUIVALENT TFLOP/s of the whole job (SURVEY.md 8(d) flops x all elements / kernel_us_avg)",
+        "executed": executed_fraction(count_key, wl.plan.max_size, res["step_s"]),
+        "traffic": None,
+    }
+    out["roofline_hbm"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                           "frac": gbs / (HBM_PEAK_GBS * world), "bytes_per_element": byts, "traffic": None}
+    if su.get("ms_per_step"):
+        out["roofline_with_allgather"] = {
+            "what": "the same algorithmic work over the stitched step's time (kernel + evaluation + all-gather of u)",
+            "frac_fp64": flops * ne_glob / (su["ms_per_step"] * 1e-3) / 1e12 / (FP64_PEAK_TFLOPS * world),
+            "xgmi_recv_GBps_per_rank": (su.get("algorithms") or {}).get(su.get("picked"), {}).get("recv_GBps_per_rank"),
+            "xgmi_peak_GBps_per_rank_inbound": 7 * 76.8}
+    if cpu_res is not None:
+        out["cpu_baseline"] = cpu_res
     for key in res:
         if key.startswith("stitch_u_"):
             out[key] = res[key]
@@ -776,7 +921,10 @@ def _varcoef_device_tables(xc):
     return a, da, f
 
 
-def run_config5(args, D, M, n, ne, lo, hi, dev, cpu_res):
+def measure_config5(D, M, n, ne, lo, hi, dev, steps, warmup, pm=True, full=True, cpu_res=None, narrow_too=False):
+    """BASELINE config 5 (one GPU): the timed region (the fused variable-coefficient step), its roofline priced
+    with the region's per-step time -- HBM is the binding roof -- the enhancement kernel's stamps beside it,
+    accuracy of what was timed; ``full`` adds the other table layout, the eager loop and the narrow domain."""
     import numpy as np
     import torch
     from hybrid_fem_lssvr_amd import ops
@@ -814,34 +962,35 @@ def run_config5(args, D, M, n, ne, lo, hi, dev, cpu_res):
             plans = [step_plan(w)]
         return timed_compute(_One, D, steps, warmup, mode=mode)
 
-    steps, warmup = args.steps, args.warmup
-    pm = args.table_layout == "point"
     w = build(ne, lo, hi, pm)
-    dev_s, wall_s = timed(w, steps, warmup)
-    timed_used = TIMED_USED[-1]
+    t = timed(w, steps, warmup)
+    step_s = t.s / steps
     eager_loop = None
-    if timed_used.startswith("graph"):
+    if full and t.mode.startswith("graph"):
         try:
-            de, we = timed(w, steps, warmup, mode="eager")
-            eager_loop = {"what": "the same K steps issued call by call from Python (one stream)",
-                          "value": ne * steps / de, "unit": "elements/s", "ms_per_step": de / steps * 1e3,
-                          "host_wall_ms_per_step": we / steps * 1e3}
+            te = timed(w, steps, warmup, mode="eager")
+            eager_loop = {"what": "the same K steps issued call by call from Python (one stream)", "unit": "elements/s",
+                          **timing_fields(te, steps, ne)}
+            eager_loop.pop("value_is")
         except Exception as exc:  # pragma: no cover
             eager_loop = {"error": repr(exc)}
     n_fallback = int(w["st"].sum().item())
-    # the kernel's stamped duration inside a running sequence (as in the timed region); isolated beside it
-    nprof = min(steps, 50)
-    enh(w, profiled=True, repeats=max(nprof, 20))                               # (untimed: steady state)
+    # the enhancement kernel ALONE, stamped inside a running sequence and in isolation: secondary figures
+    nprof = min(max(steps, 20), 50)
+    enh(w, profiled=True, repeats=nprof)                                        # (untimed: steady state)
     k_s = sorted(enh(w, profiled=True, repeats=nprof))
     k_avg, k_med = sum(k_s) / len(k_s), k_s[len(k_s) // 2]
-    k_iso = sorted(enh(w, profiled=True) for _ in range(min(steps, 20)))
+    k_iso = sorted(enh(w, profiled=True) for _ in range(20 if full else 8))
+    step_plan(w).launch()                        # (leave the step's result in W for the accuracy block)
+    torch.cuda.synchronize()
 
     # the other table layout on the same mesh (same values transposed; bit-equal W expected)
     other = None
-    try:
+    if full:
+      try:
         W_first = w["W"].clone()
         wo = dict(w, a=w["a"].t().contiguous(), da=w["da"].t().contiguous(), f=w["f"].t().contiguous(), pm=not pm)
-        do, _ = timed(wo, max(steps // 2, 5), min(warmup, 5))
+        do = timed(wo, max(steps // 2, 5), min(warmup, 5), replays=3).s
         ko = sorted(enh(wo, profiled=True) for _ in range(20))
         torch.cuda.synchronize()
         other = {"table_layout": "element-major t[e, k]" if pm else "point-major t[k, e]",
@@ -850,9 +999,9 @@ def run_config5(args, D, M, n, ne, lo, hi, dev, cpu_res):
                  "hbm_GBps": C5_BYTES_PER_ELEMENT * ne / (sum(ko) / len(ko)) / 1e9,
                  "W_bit_equal_to_primary_layout": bool(torch.equal(W_first, wo["W"]))}
         del wo, W_first
-        enh(w)                                   # leave the primary layout's result in W for the accuracy block
+        step_plan(w).launch()                    # leave the primary layout's result in W for the accuracy block
         torch.cuda.synchronize()
-    except Exception as exc:  # pragma: no cover
+      except Exception as exc:  # pragma: no cover
         other = {"error": repr(exc)}
 
     # accuracy of what was just timed: sampled elements against the 60-digit minimiser of the QP
@@ -863,7 +1012,7 @@ def run_config5(args, D, M, n, ne, lo, hi, dev, cpu_res):
         from oracle import lssvr_oracle as orc
         from oracle import closed_form_mp as cf
         a_f, da_f, f_f = orc.varcoef_functions(*orc.varcoef_params())
-        sel = np.unique(np.linspace(0, ne - 1, 7).astype(np.int64))
+        sel = np.unique(np.linspace(0, ne - 1, 7 if full else 4).astype(np.int64))
         idx = torch.as_tensor(sel, device=dev)
         xs = torch.stack([w["x"][idx], w["x"][idx + 1]], 1).cpu().numpy()
         accuracy = {"sampled_elements": int(len(sel))}
@@ -893,9 +1042,9 @@ def run_config5(args, D, M, n, ne, lo, hi, dev, cpu_res):
         accuracy = {"error": repr(exc)}
 
     narrow = None
-    if args.domain == "wide" and not args.elements:
+    if narrow_too:
         wn = build(NE_C5_NARROW, -1.0, 1.0, pm)
-        dn, _ = timed(wn, max(steps // 2, 5), min(warmup, 5))
+        dn = timed(wn, max(steps // 2, 5), min(warmup, 5), replays=3).s
         kn = sorted(enh(wn, profiled=True) for _ in range(20))
         narrow = {"workload": "%d elements on [-1, 1] (BASELINE's wording; the SLSQP baseline does not converge "
                               "there), same step" % NE_C5_NARROW,
@@ -905,18 +1054,17 @@ def run_config5(args, D, M, n, ne, lo, hi, dev, cpu_res):
 
     flops = c5_flops(M, n)
     byts = C5_BYTES_PER_ELEMENT
-    gbs = byts * ne / k_avg / 1e9
-    tfl = flops * ne / k_avg / 1e12
+    gbs = byts * ne / step_s / 1e9
+    tfl = flops * ne / step_s / 1e12
+    degree = M - 1
     out = {
-        "metric": "LSSVR-enhanced elements/sec, variable-coefficient -(a u')'=f deg-%d/%d-pt" % (args.degree, n),
-        "value": ne * steps / dev_s,
+        "metric": "LSSVR-enhanced elements/sec, variable-coefficient -(a u')'=f deg-%d/%d-pt" % (degree, n),
+        **timing_fields(t, steps, ne),
         "unit": "elements/s",
         "n_gpus": 1,
         "steps": steps,
         "warmup": warmup,
         "prewarm_steps": PREWARM_DONE,
-        "ms_per_step": dev_s / steps * 1e3,
-        "host_wall_ms_per_step": wall_s / steps * 1e3,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -928,16 +1076,16 @@ def run_config5(args, D, M, n, ne, lo, hi, dev, cpu_res):
                          "degree %d (M = %d), %d collocation points, gamma = 1e4; a, a', f tabulated per element and "
                          "point (3 x %d doubles per element, resident in HBM, %s); step = element-local P1 assembly "
                          "(a-weighted stiffness, 2-point Gauss) + per-element Gram + solve: one fused launch (lssvr_step_varcoef)"
-                         % (ne, lo, hi, (hi - lo) / ne, args.degree, M, n, n,
+                         % (ne, lo, hi, (hi - lo) / ne, degree, M, n, n,
                             "point-major t[k, e]" if pm else "element-major t[e, k]")),
             "elements_per_gpu": ne,
             "elements_total": ne,
             "parallelism": "one rank",
             "solver": "primal, BC-eliminated SPD (M-2), direct Gram of the weighted rows, LDL^T (lane per element)",
             "fallback_elements": n_fallback,
-            "timing": "HIP events around the K steps on the launch stream, device synchronised on both sides",
-            "timed_region": ("the K steps captured once in a hipGraph (untimed, like the warm-up) and replayed"
-                             if timed_used.startswith("graph") else "K launches issued call by call: " + timed_used),
+            "timing": "HIP events around exactly K steps on the launch stream, barrier + device synchronisation on "
+                      "both sides, repeated; median reported",
+            "timed_region": region_text(t.mode),
         },
         "roofline": {
             "bound": "hbm",
@@ -946,7 +1094,8 @@ def run_config5(args, D, M, n, ne, lo, hi, dev, cpu_res):
                     "streams at 5.9 TB/s (80 us for 472 B x 1e6), the kernel's 2 200 vector instructions per element "
                     "take 77 us of issue time, and the two overlap only partly -- see roofline_fp64.executed"
                     % (flops / byts)),
-            "kernel": "enhance_small_kernel<M=%d, %s, varcoef>" % (M, "RHS_ARRAY_PM" if pm else "RHS_ARRAY"),
+            "kernel": "step_small_vc_kernel<M=%d, %s> (ONE launch per step: the variable-coefficient enhancement "
+                      "blocks + the a-weighted P1 assembly blocks of the same grid)" % (M, "RHS_ARRAY_PM" if pm else "RHS_ARRAY"),
             "achieved": gbs,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -954,18 +1103,26 @@ def run_config5(args, D, M, n, ne, lo, hi, dev, cpu_res):
             "frac_of_achievable_6.29TBs": gbs / HBM_ACHIEVABLE_GBS,
             "bytes_per_element": byts,
             "elements_per_launch": ne,
-            "kernel_us_avg": k_avg * 1e6,
-            "kernel_us_isolated_avg": sum(k_iso) / len(k_iso) * 1e6,
-            "kernel_us_is": "average over %d launches issued back to back, each with its own begin -> end stamps, one "
-                            "synchronisation at the end (kernel_us_isolated_avg: a synchronisation around every launch)" % nprof,
-            "kernel_us_median": k_med * 1e6,
+            "kernel_us_avg": step_s * 1e6,
+            "kernel_us_is": "launch-to-launch duration of the step's kernel INSIDE THE TIMED REGION = the median bracket / K "
+                            "(HIP events on the launch stream); rocprofv3 --kernel-trace --stats of the same command "
+                            "(profiles/) reads the kernel's begin -> end stamps, which must agree to a few %",
+            "enhancement_only": {
+                "kernel": "enhance_small_kernel<M=%d, %s, varcoef>" % (M, "RHS_ARRAY_PM" if pm else "RHS_ARRAY"),
+                "what": "the enhancement WITHOUT the assembly blocks, begin -> end stamps of the dispatch",
+                "kernel_us_in_sequence_avg": k_avg * 1e6,
+                "kernel_us_in_sequence_median": k_med * 1e6,
+                "kernel_us_isolated_avg": sum(k_iso) / len(k_iso) * 1e6,
+                "launches": nprof,
+                "frac_in_sequence": byts * ne / k_avg / 1e9 / HBM_PEAK_GBS,
+            },
             "traffic": None,
             "traffic_source": None,
         },
         "roofline_fp64": {
             "bound": "fp64-valu",
             "executed": executed_fraction("c5_point_major_M%d_n%d" % (M, n) if pm else "c5_element_major_M%d_n%d" % (M, n),
-                                          ne, k_avg),
+                                          ne, step_s),
             "achieved": tfl,
             "peak": FP64_PEAK_TFLOPS,
             "unit": "TFLOP/s",
@@ -1000,19 +1157,88 @@ def run_config5(args, D, M, n, ne, lo, hi, dev, cpu_res):
 
 
 # ----------------------------------------------------------------------------------------
-# N = 1
+# N = 1, Poisson rows (BASELINE configs 2 and 4, the 1e7-element mesh, the dual solver)
 # ----------------------------------------------------------------------------------------
-def run_single(args, D, M, n, ne_glob, lo, hi, dev, cpu_res, use_dist):
+def poisson_labels(M, n, dual):
+    """(kernel of the timed step, enhancement kernel, pipe text, solver text, instruction-count key)."""
+    if dual:
+        big = max(M, n) > 32
+        enh = "enhance_dual_w64_kernel" if big else "enhance_dual_kernel"
+        return ("p1_assemble_kernel + %s (two launches per step)" % enh, enh,
+                "FP64 vector FMA only (row per lane: Gram by scalar FMAs, partial-pivot LU with the pivot row "
+                + ("read out of the pivot lane by v_readfirstlane, two waves per SIMD" if big else "through LDS")
+                + ", <= 3 safeguarded refinement steps); no MFMA is issued",
+                "dual Gram form (K + I/gamma) alpha = y: boundary block pivot, Jacobi equilibration, partial-pivot LU",
+                "dual_M%d_n%d" % (M, n))
+    if M <= 22:
+        return ("step_small_kernel<M=%d> (ONE launch per step: the per-element enhancement blocks + the P1 assembly "
+                "blocks of the same grid)" % M, "enhance_small_kernel<M=%d, RHS_SIN>" % M,
+                "FP64 vector FMA only (lane per element, no MFMA issued); the FP64 vector and matrix peaks of "
+                "gfx950 are the same 78.6 TFLOP/s and share one pipe (DESIGN.md section 3)",
+                "primal, BC-eliminated SPD (M-2), Chebyshev-moment Gram, LDL^T", "small_M%d_n%d_sin" % (M, n))
+    second = "solve4_parity_kernel" if n >= 2 * (M - 2) else "solve4_kernel (+ refinement kernels when n <= M + 12)"
+    return ("p1_assemble_kernel + moments_kernel + %s (three launches per step)" % second,
+            "moments_kernel + %s (the pair, gap included)" % second,
+            "FP64 vector pipe: Chebyshev moments (lane per element) + parity-split four-systems-per-wave "
+            "DPP-broadcast LDL^T (persistent waves); it executes about a quarter of the flops the formula "
+            "prices, so frac can exceed what a direct Gram could reach; the f64-MFMA Gram kernel "
+            "(LSSVR_SOLVER_PRIMAL_WAVE) is 2x slower (DESIGN.md section 3.8); vector and matrix FP64 share one "
+            "pipe at the same 78.6 TFLOP/s peak",
+            "primal, BC-eliminated SPD (M-2), Chebyshev-moment Gram, parity-split LDL^T + coupling "
+            "iteration (two kernels, workspace)", "large_pair_M%d_n%d" % (M, n))
+
+
+def poisson_accuracy(wl, W, M, n, dev, nsel=9, ntruth=5):
+    """Accuracy of what was just timed (reported with every timing): sampled elements against
+    the float64 KKT oracle and the 60-digit minimiser (whole polynomial and the enhancement alone), and the
+    stitched u(x) against sin(pi x) on a probe grid."""
     import numpy as np
     import torch
     from hybrid_fem_lssvr_amd import ops
+    try:
+        from oracle import lssvr_oracle as orc
+        from oracle import closed_form_mp as cf
+        nodes_h, values_h, ne = wl.nodes_h, wl.values_h, wl.ne_loc
+        sel = np.unique(np.linspace(0, ne - 1, nsel).astype(np.int64))
+        W_sel = W[torch.as_tensor(sel, device=dev)].cpu().numpy()
+
+        def system(i):
+            return orc.element_system(nodes_h[i], nodes_h[i + 1],
+                                      *orc.boundary_values(int(i), wl.ne_glob, nodes_h[i], nodes_h[i + 1],
+                                                           values_h[i], values_h[i + 1], wl.gd), M, GAMMA, n)
+        Wo = np.array([orc.solve_primal_kkt(system(i)) for i in sel])
+        acc = {"sampled_elements": int(len(sel)),
+               "rel_l2_vs_float64_kkt_oracle": float(orc.rel_l2_coef(W_sel, Wo).max())}
+        if cf.HAVE_MP:
+            tr = np.array([cf.solve_truth(system(i)) for i in sel[:ntruth]])
+            acc["rel_l2_vs_60_digit_minimiser"] = float(orc.rel_l2_coef(W_sel[:ntruth], tr).max())
+            acc["rel_l2_bubble_vs_60_digit_minimiser"] = float(orc.rel_l2_bubble(W_sel[:ntruth], tr).max())
+        xq_h = np.linspace(nodes_h[0], nodes_h[-1], 20001)
+        norms = ops.eval_error(wl.x, W, torch.as_tensor(xq_h, device=dev)).cpu().numpy()
+        acc["rel_l2_vs_sin_pi_x_on_20001_probes"] = float(np.sqrt(norms[0] / norms[1]))
+        acc["max_abs_err_vs_sin_pi_x"] = float(norms[2])
+        acc["note"] = ("nodal values are sin(pi x_i) here (device-resident synthetic input), so the "
+                       "last figure is the enhancement's own error, not the P1 nodal error")
+        return acc
+    except Exception as exc:  # pragma: no cover
+        return {"error": repr(exc)}
+
+
+def measure_poisson(D, M, n, ne_glob, lo, hi, dev, steps, warmup, solver="primal", full=True, cpu_res=None,
+                    use_dist=False, label=""):
+    """One N = 1 line of the Poisson path: the timed region (``timed_compute``), the roofline of the KERNEL(S) THE
+    TIMED REGION LAUNCHES priced with the region's own per-step time, the enhancement kernel's stamped durations
+    beside it, accuracy of what was timed; ``full`` adds the secondary measurements of the headline line."""
+    import torch
+    from hybrid_fem_lssvr_amd import ops
+    degree = M - 1
     wl = Workload(ne_glob, lo, hi, M, n, 0, 1, dev)
     ne_loc = wl.ne_loc
     x, u, W, status, gd = wl.x, wl.u, wl.W[0], wl.status, wl.gd
-    solver_id = ops.SOLVER_DUAL if args.solver == "dual" else ops.SOLVER_PRIMAL
+    dual = solver == "dual"
+    solver_id = ops.SOLVER_DUAL if dual else ops.SOLVER_PRIMAL
     st = torch.cuda.current_stream().cuda_stream
-
-    if args.solver == "dual":
+    if dual:
         # the dual Gram solver has no fused step: a step is assembly + enhancement, two launches
         class _TwoLaunch:
             def launch(self, s=None):
@@ -1020,120 +1246,200 @@ def run_single(args, D, M, n, ne_glob, lo, hi, dev, cpu_res, use_dist):
                 ops.enhance(x, u, M, GAMMA, n, global_domain=gd, solver=solver_id, out=W, status=status, stream=s)
         _TwoLaunch.W, _TwoLaunch.status = W, status
         wl.plans = [_TwoLaunch()]
-    dev_s, wall_s = timed_compute(wl, D, args.steps, args.warmup)
-    timed_used = TIMED_USED[-1]
-    elapsed = dev_s
+    t = timed_compute(wl, D, steps, warmup)
     n_fallback = int(status.sum().item())
+    step_s = t.s / steps
+
+    # the per-element enhancement kernel ALONE (no assembly blocks), from HIP events that hipExtLaunchKernelGGL
+    # stamps with the dispatch's own begin / end times -- rocprofv3's kernel duration -- inside a running sequence
+    # of the same launches and in isolation: SECONDARY figures; `roofline.frac` is priced with the timed region
+    nprof = min(max(steps, 20), 100)
+    ops.enhance_profiled(x, u, M, GAMMA, n, global_domain=gd, out=W, status=status, solver=solver_id,
+                         repeats=nprof)                                           # (untimed: steady state)
+    k_s = sorted(ops.enhance_profiled(x, u, M, GAMMA, n, global_domain=gd, out=W, status=status,
+                                      solver=solver_id, repeats=nprof))
+    k_avg, k_med = sum(k_s) / len(k_s), k_s[len(k_s) // 2]
+    k_iso = sorted(ops.enhance_profiled(x, u, M, GAMMA, n, global_domain=gd, out=W, status=status, solver=solver_id)
+                   for _ in range(20 if full else 8))
+    wl.plans[0].launch(st)                       # (leave the step's result in W for the accuracy block)
+    torch.cuda.synchronize()
+
+    flops = algorithmic_flops_dual(M, n) if dual else algorithmic_flops(M, n)
+    byts = algorithmic_bytes(M)
+    step_kernel, enh_kernel, pipe, solver_lbl, count_key = poisson_labels(M, n, dual)
+    ach = flops * ne_loc / step_s / 1e12
+    out = {
+        "metric": "LSSVR-enhanced elements/sec, 1D Poisson deg-%d/%d-pt" % (degree, n),
+        **timing_fields(t, steps, ne_glob),
+        "unit": "elements/s",
+        "n_gpus": 1,
+        "steps": steps,
+        "warmup": warmup,
+        "prewarm_steps": PREWARM_DONE,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": wl.describe(degree) + label,
+            "elements_per_gpu": ne_loc,
+            "elements_total": ne_glob,
+            "parallelism": "one rank",
+            "solver": solver_lbl,
+            "fallback_elements": n_fallback,
+            "timing": "HIP events around exactly K steps on the launch stream, barrier + device synchronisation on "
+                      "both sides, repeated; median reported",
+            "timed_region": region_text(t.mode),
+        },
+        "roofline": {
+            "bound": "fp64-valu",
+            "pipe": pipe,
+            "kernel": step_kernel,
+            "achieved": ach,
+            "peak": FP64_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": ach / FP64_PEAK_TFLOPS,
+            "flops_per_element": flops,
+            "flops_formula": "SURVEY.md 8(d) " + ("dual" if dual else "primal") + " form (direct Gram); the kernel's "
+                             "Chebyshev-moment Gram executes fewer (DESIGN.md section 2b)",
+            "achieved_is": "direct-Gram-EQUIVALENT TFLOP/s (algorithmic flops of SURVEY.md 8(d) x elements per launch / "
+                           "kernel_us_avg), not executed flops: see `executed`",
+            "elements_per_launch": ne_loc,
+            "kernel_us_avg": step_s * 1e6,
+            "kernel_us_is": "launch-to-launch duration of the step's kernel(s) INSIDE THE TIMED REGION = the median "
+                            "bracket / K (HIP events on the launch stream): the kernel's own duration plus the "
+                            "boundary to the next dependent launch; rocprofv3 --kernel-trace --stats of the same "
+                            "command (profiles/) reads the kernel's begin -> end stamps, which must agree to a few %",
+            "executed": executed_fraction(count_key, ne_loc, step_s),
+            "enhancement_only": {
+                "kernel": enh_kernel,
+                "what": "the enhancement WITHOUT the assembly blocks, begin -> end stamps of the dispatch "
+                        "(hipExtLaunchKernelGGL events = rocprofv3's kernel duration)",
+                "kernel_us_in_sequence_avg": k_avg * 1e6,
+                "kernel_us_in_sequence_median": k_med * 1e6,
+                "kernel_us_isolated_avg": sum(k_iso) / len(k_iso) * 1e6,
+                "launches": nprof,
+                "frac_in_sequence": flops * ne_loc / k_avg / 1e12 / FP64_PEAK_TFLOPS,
+            },
+            "traffic": None,
+            "traffic_source": None,
+        },
+        "roofline_hbm": {
+            "bound": "hbm",
+            "achieved": byts * ne_loc / step_s / 1e9,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": byts * ne_loc / step_s / 1e9 / HBM_PEAK_GBS,
+            "bytes_per_element": byts,
+            "traffic": None,
+        },
+    }
+    tf = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tf) and not dual:
+        try:
+            tj = json.load(open(tf))
+            tr = tj.get("M%d_n%d_ne%d" % (M, n, ne_loc))
+            if tr:
+                out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+                out["roofline_hbm"]["traffic"] = tr["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = ("profiles/traffic.json (%s): %s; NOT measured in this run"
+                                                     % (tj.get("_round", "committed profile"),
+                                                        tr.get("what", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                                                       "at this size, calibrated")))
+        except Exception:
+            pass
+    out["accuracy"] = poisson_accuracy(wl, W, M, n, dev, nsel=9 if full else 5, ntruth=5 if (full and M <= 22) else 3)
+    if cpu_res is not None:
+        out["cpu_baseline"] = cpu_res
+    if not full:
+        return out
+
+    try:
+        out["roofline"]["fp64_fma_probe_tflops"] = round(ops.fp64_probe(8192, 4096, False), 2)
+        if M > 22 or dual:
+            out["roofline"]["fp64_mfma_4x4x4_probe_tflops"] = round(ops.fp64_probe(8192, 2048, 3), 2)
+            out["roofline"]["fp64_mfma_16x16x4_probe_tflops"] = round(ops.fp64_probe(8192, 1024, 1), 2)
+    except Exception as exc:  # pragma: no cover
+        out["roofline"]["fp64_fma_probe_tflops"] = "failed: %s" % exc
 
     # RCCL bring-up with one rank (LSSVR_BENCH_FORCE_DIST=1): both stitches once
-    forced = None
     if use_dist:
         try:
             wl2 = Workload(ne_glob, lo, hi, M, n, 0, 1, dev, nbuf=2)
-            forced = {w: timed_stitch(wl2, D, 5, 2, w, a) for w in ("u", "W") for a in ("collective",)}
+            out["forced_dist_single_rank"] = {w: timed_stitch(wl2, D, 5, 2, w, a) for w in ("u", "W")
+                                              for a in ("collective", "pairs")}
+            del wl2
         except Exception as exc:  # pragma: no cover
-            forced = {"error": repr(exc)}
+            out["forced_dist_single_rank"] = {"error": repr(exc)}
 
-    # dominant kernel (the per-element enhancement): launch duration from HIP events that
-    # hipExtLaunchKernelGGL stamps with the dispatch's own begin / end times -- the quantity
-    # rocprofv3 --kernel-trace reports -- over the same launch as in the timed region,
-    # right after it (a plain hipEventRecord pair adds ~4 us of dispatch latency)
-    # ... INSIDE a running sequence of the same launches (lssvr_enhance_ws_sequence: every launch stamped, one
-    # synchronisation at the end), as in the timed region; the same launch in isolation (an idle chip before and
-    # after every one) is reported beside it
-    nprof = min(args.steps, 100)
-    ops.enhance_profiled(x, u, M, GAMMA, n, global_domain=gd, out=W, status=status, solver=solver_id,
-                         repeats=max(nprof, 20))                                  # (untimed: steady state)
-    k_s = sorted(ops.enhance_profiled(x, u, M, GAMMA, n, global_domain=gd, out=W, status=status,
-                                      solver=solver_id, repeats=nprof))
-    k_avg = sum(k_s) / len(k_s)
-    k_med = k_s[len(k_s) // 2]
-    k_iso = sorted(ops.enhance_profiled(x, u, M, GAMMA, n, global_domain=gd, out=W, status=status,
-                                        solver=solver_id)
-                   for _ in range(min(args.steps, 30)))
-
-    default_run = (args.domain == "wide" and not args.elements and args.solver == "primal")
-    # the same step on exactly 1e5 elements of [-1, 1] (BASELINE.json's wording of config 2),
-    # where the CPU baseline cannot be timed (SURVEY.md finding 5): shows that the kernel cost
-    # does not depend on the domain
-    narrow = None
-    if default_run:
-        wn = Workload(NE_NARROW, -1.0, 1.0, M, n, 0, 1, dev)
-        dn, _ = timed_compute(wn, D, args.steps, args.warmup)
-        narrow = {"workload": "%d elements on [-1, 1], same step" % NE_NARROW,
-                  "value": NE_NARROW * args.steps / dn, "ms_per_step": dn / args.steps * 1e3,
-                  "fallback_elements": int(wn.status.sum().item())}
+    # the OTHER way of issuing the same K steps (see TIMED_MODE), same plan, same buffers: reported beside `value`
+    try:
+        alt = "eager" if t.mode.startswith("graph") else "graph"
+        W_ref = W.clone()
+        ta = timed_compute(wl, D, steps, warmup, mode=alt)
+        other = {"what": ("the same K steps issued call by call from Python (one stream)" if alt == "eager"
+                          else "the same K steps captured once in a hipGraph (one stream) and replayed"),
+                 "mode_used": ta.mode, **timing_fields(ta, steps, ne_glob), "unit": "elements/s",
+                 "results_equal": bool(torch.equal(W_ref, W))}
+        other.pop("value_is")
+        out["eager_loop" if alt == "eager" else "graph_replay"] = other
+        del W_ref
+    except Exception as exc:  # pragma: no cover
+        out["other_timed_mode"] = {"error": repr(exc)}
+    if dual:
+        return out
 
     # the same K steps issued round-robin on two HIP streams with separate output buffers: at
     # 1e5 elements one launch fills only ~60 % of the chip's wave slots, so independent batches
     # overlap.  Reported beside `value` (which is strictly sequential on one stream).
-    pipelined = None
-    if args.solver == "primal":
-        try:
-            nstream = 2
-            streams = [torch.cuda.Stream(device=dev) for _ in range(nstream)]
-            wp = [Workload(ne_glob, lo, hi, M, n, 0, 1, dev) for _ in range(nstream)]
-            torch.cuda.synchronize()
-            for i in range(args.warmup):
-                wp[i % nstream].plans[0].launch(streams[i % nstream].cuda_stream)
-            torch.cuda.synchronize()
-            tp = time.perf_counter()
-            for i in range(args.steps):
-                wp[i % nstream].plans[0].launch(streams[i % nstream].cuda_stream)
-            torch.cuda.synchronize()
-            tp = time.perf_counter() - tp
-            pipelined = {"what": "same K steps, round-robin on %d streams, separate W buffers" % nstream,
-                         "streams": nstream, "value": ne_loc * args.steps / tp, "unit": "elements/s",
-                         "ms_per_step": tp / args.steps * 1e3,
-                         "results_equal": bool(torch.equal(wp[0].W[0], W) and torch.equal(wp[1].W[0], W))}
-            del wp
-        except Exception as exc:  # pragma: no cover
-            pipelined = {"error": repr(exc)}
-
-    # the OTHER way of issuing the same K steps (see TIMED_MODE), same plan, same buffers: reported beside `value`
-    other_mode = None
-    if True:
-        try:
-            alt = "eager" if timed_used.startswith("graph") else "graph"
-            W_ref = W.clone()
-            da, wa = timed_compute(wl, D, args.steps, args.warmup, mode=alt)
-            other_mode = {"what": ("the same K steps issued call by call from Python (one stream)" if alt == "eager"
-                                   else "the same K steps captured once in a hipGraph (one stream) and replayed"),
-                          "mode_used": TIMED_USED[-1],
-                          "value": ne_loc * args.steps / da, "unit": "elements/s",
-                          "ms_per_step": da / args.steps * 1e3, "host_wall_ms_per_step": wa / args.steps * 1e3,
-                          "results_equal": bool(torch.equal(W_ref, W))}
-            del W_ref
-            other_key = "eager_loop" if alt == "eager" else "graph_replay"
-        except Exception as exc:  # pragma: no cover
-            other_mode, other_key = {"error": repr(exc)}, "other_timed_mode"
+    try:
+        nstream = 2
+        streams = [torch.cuda.Stream(device=dev) for _ in range(nstream)]
+        wp = [Workload(ne_glob, lo, hi, M, n, 0, 1, dev) for _ in range(nstream)]
+        torch.cuda.synchronize()
+        for i in range(warmup):
+            wp[i % nstream].plans[0].launch(streams[i % nstream].cuda_stream)
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        for i in range(steps):
+            wp[i % nstream].plans[0].launch(streams[i % nstream].cuda_stream)
+        torch.cuda.synchronize()
+        tp = time.perf_counter() - tp
+        out["pipelined"] = {"what": "same K steps, round-robin on %d streams, separate W buffers (host clock)" % nstream,
+                            "streams": nstream, "value": ne_loc * steps / tp, "unit": "elements/s",
+                            "ms_per_step": tp / steps * 1e3,
+                            "results_equal": bool(torch.equal(wp[0].W[0], W) and torch.equal(wp[1].W[0], W))}
+        del wp
+    except Exception as exc:  # pragma: no cover
+        out["pipelined"] = {"error": repr(exc)}
 
     # the uniform-mesh shortcut (lssvr_enhance_shared; SURVEY.md 8(d): "reported as a separate line
     # if built"): one shared operator applied per element.  Never part of `value`; its own
     # roofline is HBM (88 B per element against ~8 TB/s).
-    shared = None
-    if M <= 33 and args.solver == "primal":
-        try:
-            op = ops.build_shared_operator((hi - lo) / ne_glob, M, GAMMA, n, device=dev)
-            Ws = torch.empty((ne_loc, M), dtype=torch.float64, device=dev)
-            ts = sorted(ops.enhance_shared(x, u, op, M, n, global_domain=gd, out=Ws, status=status, profiled=True)
-                        for _ in range(min(args.steps, 50)))
-            t_sh = sum(ts) / len(ts)
-            diff = (Ws - W).double()
-            rel = float((diff.pow(2).sum(1).sqrt() / W.pow(2).sum(1).sqrt().clamp_min(1e-300)).max().item())
-            shared = {
-                "what": "lssvr_enhance_shared: uniform mesh, one (n+2) x M operator (built by the general "
-                        "kernel) applied per element; same inputs, same W layout",
-                "value": ne_loc / t_sh, "unit": "elements/s", "kernel_us_avg": t_sh * 1e6,
-                "kernel_us_median": ts[len(ts) // 2] * 1e6,
-                "roofline": {"bound": "hbm", "achieved": algorithmic_bytes(M) * ne_loc / t_sh / 1e9,
-                             "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": algorithmic_bytes(M) * ne_loc / t_sh / 1e9 / HBM_PEAK_GBS,
-                             "bytes_per_element": algorithmic_bytes(M)},
-                "max_rel_coef_diff_vs_general_kernel": rel,
-            }
-        except Exception as exc:  # pragma: no cover
-            shared = {"error": repr(exc)}
+    try:
+        op = ops.build_shared_operator((hi - lo) / ne_glob, M, GAMMA, n, device=dev)
+        Ws = torch.empty((ne_loc, M), dtype=torch.float64, device=dev)
+        ts = sorted(ops.enhance_shared(x, u, op, M, n, global_domain=gd, out=Ws, status=status, profiled=True)
+                    for _ in range(min(max(steps, 20), 50)))
+        t_sh = sum(ts) / len(ts)
+        diff = (Ws - W).double()
+        rel = float((diff.pow(2).sum(1).sqrt() / W.pow(2).sum(1).sqrt().clamp_min(1e-300)).max().item())
+        out["shared_operator"] = {
+            "what": "lssvr_enhance_shared: uniform mesh, one (n+2) x M operator (built by the general "
+                    "kernel) applied per element; same inputs, same W layout",
+            "value": ne_loc / t_sh, "unit": "elements/s", "kernel_us_avg": t_sh * 1e6,
+            "kernel_us_median": ts[len(ts) // 2] * 1e6,
+            "roofline": {"bound": "hbm", "achieved": algorithmic_bytes(M) * ne_loc / t_sh / 1e9,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": algorithmic_bytes(M) * ne_loc / t_sh / 1e9 / HBM_PEAK_GBS,
+                         "bytes_per_element": algorithmic_bytes(M)},
+            "max_rel_coef_diff_vs_general_kernel": rel,
+        }
+        wl.plans[0].launch(st)
+        torch.cuda.synchronize()
+    except Exception as exc:  # pragma: no cover
+        out["shared_operator"] = {"error": repr(exc)}
 
     # the stages around the hot path, each timed on its own (t_global_solve,
     # t_eval, H2D/D2H are reported separately and never enter `value`)
@@ -1174,169 +1480,10 @@ def run_single(args, D, M, n, ne_glob, lo, hi, dev, cpu_res, use_dist):
         wl.plans[0].launch(st)
         torch.cuda.synchronize()
         hd = stages["h2d_nodes_and_values_us"] + stages["d2h_coefficients_us"]
-        stages["pcie_inclusive_elements_per_s"] = ne_loc / ((elapsed / args.steps) + hd * 1e-6)
+        stages["pcie_inclusive_elements_per_s"] = ne_loc / (step_s + hd * 1e-6)
+        out["stages"] = stages
     except Exception as exc:  # pragma: no cover
-        stages = {"error": repr(exc)}
-
-    # accuracy of what was just timed (reported with every timing): sampled
-    # elements against the float64 KKT oracle (and the 60-digit minimiser when mpmath is
-    # present), and the stitched u(x) against sin(pi x) on a probe grid
-    try:
-        from oracle import lssvr_oracle as orc
-        from oracle import closed_form_mp as cf
-        nodes_h, values_h = wl.nodes_h, wl.values_h
-        W_h = W.cpu().numpy()
-        sel = np.unique(np.linspace(0, ne_loc - 1, 9).astype(np.int64))
-
-        def system(i):
-            return orc.element_system(nodes_h[i], nodes_h[i + 1],
-                                      *orc.boundary_values(int(i), ne_glob, nodes_h[i], nodes_h[i + 1],
-                                                           values_h[i], values_h[i + 1], gd), M, GAMMA, n)
-        Wo = np.array([orc.solve_primal_kkt(system(i)) for i in sel])
-        accuracy = {"sampled_elements": int(len(sel)),
-                    "rel_l2_vs_float64_kkt_oracle": float(orc.rel_l2_coef(W_h[sel], Wo).max())}
-        if cf.HAVE_MP:
-            tr = np.array([cf.solve_truth(system(i)) for i in sel[:5]])
-            accuracy["rel_l2_vs_60_digit_minimiser"] = float(orc.rel_l2_coef(W_h[sel[:5]], tr).max())
-        xq_h = np.linspace(nodes_h[0], nodes_h[-1], 20001)
-        norms = ops.eval_error(x, W, torch.as_tensor(xq_h, device=dev)).cpu().numpy()
-        accuracy["rel_l2_vs_sin_pi_x_on_20001_probes"] = float(np.sqrt(norms[0] / norms[1]))
-        accuracy["max_abs_err_vs_sin_pi_x"] = float(norms[2])
-        accuracy["note"] = ("nodal values are sin(pi x_i) here (device-resident synthetic input), so the "
-                            "last figure is the enhancement's own error, not the P1 nodal error")
-    except Exception as exc:  # pragma: no cover
-        accuracy = {"error": repr(exc)}
-
-    total = ne_glob * args.steps
-    dual = args.solver == "dual"
-    flops = algorithmic_flops_dual(M, n) if dual else algorithmic_flops(M, n)
-    byts = algorithmic_bytes(M)
-    k_dur = max(k_avg, 1e-9)
-    ach_tflops = flops * ne_loc / k_dur / 1e12
-    if dual:
-        big = max(M, n) > 32
-        kernel_name, bound = ("enhance_dual_w64_kernel" if big else "enhance_dual_kernel"), "fp64-valu"
-        pipe = ("FP64 vector FMA only (row per lane: Gram by scalar FMAs, partial-pivot LU with the pivot row "
-                + ("read out of the pivot lane by v_readlane, two waves per SIMD" if big else "through LDS")
-                + ", <= 3 safeguarded refinement steps); no MFMA is issued")
-        solver_lbl = "dual Gram form (K + I/gamma) alpha = y: boundary block pivot, Jacobi equilibration, partial-pivot LU"
-    elif M <= 22:
-        kernel_name, bound = "enhance_small_kernel<M=%d>" % M, "fp64-valu"
-        pipe = ("FP64 vector FMA only (lane per element, no MFMA issued); the FP64 vector and matrix peaks of "
-                "gfx950 are the same 78.6 TFLOP/s and share one pipe (DESIGN.md section 3)")
-        solver_lbl = "primal, BC-eliminated SPD (M-2), Chebyshev-moment Gram, LDL^T"
-    else:
-        second = "solve4_parity_kernel" if n >= 2 * (M - 2) else "solve4_kernel (+ refinement kernels when n <= M + 12)"
-        kernel_name, bound = "moments_kernel + %s (the sequence, gaps included)" % second, "fp64-valu"
-        pipe = ("FP64 vector pipe: Chebyshev moments (lane per element) + parity-split four-systems-per-wave "
-                "DPP-broadcast LDL^T (persistent waves); it executes about a quarter of the flops the formula "
-                "prices, so frac can exceed what a direct Gram could reach; the f64-MFMA Gram kernel "
-                "(LSSVR_SOLVER_PRIMAL_WAVE) is 2x slower (DESIGN.md section 3.8); vector and matrix FP64 share one "
-                "pipe at the same 78.6 TFLOP/s peak")
-        solver_lbl = ("primal, BC-eliminated SPD (M-2), Chebyshev-moment Gram, parity-split LDL^T + coupling "
-                      "iteration (two kernels, workspace)")
-    out = {
-        "metric": "LSSVR-enhanced elements/sec, 1D Poisson deg-%d/%d-pt" % (args.degree, n),
-        "value": total / elapsed,
-        "unit": "elements/s",
-        "n_gpus": 1,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "prewarm_steps": PREWARM_DONE,
-        "ms_per_step": elapsed / args.steps * 1e3,
-        "host_wall_ms_per_step": wall_s / args.steps * 1e3,
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "f64",
-        "data": "synthetic",
-        "config": {
-            "workload": wl.describe(args.degree) + ("; BASELINE config 2" if default_run else ""),
-            "elements_per_gpu": ne_loc,
-            "elements_total": ne_glob,
-            "parallelism": "one rank",
-            "solver": solver_lbl,
-            "fallback_elements": n_fallback,
-            "timing": "HIP events around the K steps on the launch stream, device synchronised on both sides",
-            "timed_region": ("the K steps captured once in a hipGraph (untimed, like the warm-up) and replayed" if timed_used.startswith("graph")
-                             else "K launches issued call by call: " + timed_used),
-        },
-        "roofline": {
-            "bound": bound,
-            "pipe": pipe,
-            "kernel": kernel_name,
-            "achieved": ach_tflops,
-            "peak": FP64_PEAK_TFLOPS,
-            "unit": "TFLOP/s",
-            "frac": ach_tflops / FP64_PEAK_TFLOPS,
-            "flops_per_element": flops,
-            "flops_formula": "SURVEY.md 8(d) " + ("dual" if dual else "primal") + " form (direct Gram); the kernel's "
-                             "Chebyshev-moment Gram executes fewer (DESIGN.md section 2b)",
-            "achieved_is": "direct-Gram-EQUIVALENT TFLOP/s (algorithmic flops of SURVEY.md 8(d) / measured duration), "
-                           "not executed flops: see `executed`",
-            "executed": executed_fraction(("dual_M%d_n%d" % (M, n)) if dual else
-                                          ("small_M%d_n%d_sin" % (M, n)) if M <= 22 else
-                                          ("large_pair_M%d_n%d" % (M, n)), ne_loc, k_dur),
-            "elements_per_launch": ne_loc,
-            "kernel_us_avg": k_dur * 1e6,
-            "kernel_us_median": k_med * 1e6,
-            "kernel_us_isolated_avg": sum(k_iso) / len(k_iso) * 1e6,
-            "kernel_us_is": "average over %d launches of the enhancement issued back to back, each with its own "
-                            "begin -> end stamps, one synchronisation at the end (kernel_us_isolated_avg: the same "
-                            "launch with a synchronisation around every one).  " % nprof +
-                            "begin -> end stamps of the dispatch (hipExtLaunchKernelGGL events = rocprofv3's kernel "
-                            "duration).  They include ~4.1 us of dispatch that an EMPTY kernel also reads and of which "
-                            "~1 us overlaps the previous launch in a back-to-back sequence (empty kernel: 4.1 us stamped, "
-                            "3.1 us per launch back to back; profiles/r03_launch_floor.txt) -- so ms_per_step of K "
-                            "back-to-back steps can be SMALLER than this duration at 1e5 elements; it is not a "
-                            "different amount of work",
-            "traffic": None,
-            "traffic_source": None,
-        },
-        "roofline_hbm": {
-            "bound": "hbm",
-            "achieved": byts * ne_loc / k_dur / 1e9,
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": byts * ne_loc / k_dur / 1e9 / HBM_PEAK_GBS,
-            "bytes_per_element": byts,
-            "traffic": None,
-        },
-    }
-    tf = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tf) and not dual:
-        try:
-            tj = json.load(open(tf))
-            tr = tj.get("M%d_n%d_ne%d" % (M, n, ne_loc))
-            if tr:
-                out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
-                out["roofline_hbm"]["traffic"] = tr["hbm_bytes_per_launch"]
-                out["roofline"]["traffic_source"] = ("profiles/traffic.json (%s): rocprofv3 --pmc FETCH_SIZE / "
-                                                     "WRITE_SIZE passes of this kernel at this size, calibrated; "
-                                                     "NOT measured in this run" % tj.get("_round", "committed profile"))
-        except Exception:
-            pass
-    try:
-        out["roofline"]["fp64_fma_probe_tflops"] = round(ops.fp64_probe(8192, 4096, False), 2)
-        if M > 22 or dual:
-            out["roofline"]["fp64_mfma_4x4x4_probe_tflops"] = round(ops.fp64_probe(8192, 2048, 3), 2)
-            out["roofline"]["fp64_mfma_16x16x4_probe_tflops"] = round(ops.fp64_probe(8192, 1024, 1), 2)
-    except Exception as exc:  # pragma: no cover
-        out["roofline"]["fp64_fma_probe_tflops"] = "failed: %s" % exc
-    out["stages"] = stages
-    if narrow is not None:
-        out["narrow_domain"] = narrow
-    if shared is not None:
-        out["shared_operator"] = shared
-    if pipelined is not None:
-        out["pipelined"] = pipelined
-    if other_mode is not None:
-        out[other_key] = other_mode
-    out["accuracy"] = accuracy
-    if cpu_res is not None:
-        out["cpu_baseline"] = cpu_res
-    if forced is not None:
-        out["forced_dist_single_rank"] = forced
+        out["stages"] = {"error": repr(exc)}
     return out
 
 

@@ -81,7 +81,8 @@ struct ChebSlow {
   static constexpr int kZ0 = kC1 + MR;              // work: C_z = C Y
   static constexpr int kZ1 = kZ0 + MR;
   static constexpr int kRes = kZ1 + MR;             // cheb_ridge_solve's result: w[M]
-  static constexpr int kSize = kRes + M;
+  static constexpr int kFlag = kRes + M;            // this lane: 0 keeps its own result, +1 takes kRes, -1 kRes failed
+  static constexpr int kSize = kFlag + 1;
 };
 
 template <int M>
@@ -228,6 +229,8 @@ __device__ __attribute__((noinline)) bool cheb_ridge_solve(double* __restrict__ 
   }
   buf[L::kRes] = w0;
   buf[L::kRes + 1] = w1;
+#pragma nounroll
+  for (int i = 0; i < M; ++i) ok = ok && (fabs(buf[L::kRes + i]) < 1.0e300);
   return ok;
 }
 
@@ -246,6 +249,10 @@ __device__ __forceinline__ void enhance_small_body_cheb(const EnhanceArgs& p, co
   const int64_t e = (int64_t)block * kBlock + tid;
   double w[M];
   int st = LSSVR_ST_OK;
+  // cold paths' per-lane scratch (never touched by a wave that stays on the fast path) and the lane's
+  // verdict on the ridge-dominated solve parked in it (ChebSlow<M>::kFlag)
+  [[maybe_unused]] double slowbuf[MR > 0 ? ChebSlow<M>::kSize : 1];
+  [[maybe_unused]] double rflag = 0.0;
 #if LSSVR_DECOMP == 1
   if (p.ne >= 0) return;
 #endif
@@ -304,17 +311,13 @@ __device__ __forceinline__ void enhance_small_body_cheb(const EnhanceArgs& p, co
     const double idet = 0.5 * fma(sig, 1.0 + sig, 1.0);            // 1 / (tb - ta) = 1 / (2 - 2 sigma)
     constexpr double kAmax = 0.5 * (double)((M - 1) * M);
     // (a non-finite map -- degenerate element -- is not "slow": it ends in the status test)
-    const bool slow = kAmax * fmax(fabs(ea), fabs(eb)) >= 1.0e-6;
+    // ... or a RIDGE-DOMINATED element (header comment): the wave then takes the same cold branches
+    // (exact boundary rows for every lane) and, inside them, the Legendre-bubble solve for those lanes
+    const bool slow = kAmax * fmax(fabs(ea), fabs(eb)) >= 1.0e-6 || (MR > 0 && ridge_dominated(eps2, M));
     const bool any_slow = __any(slow);
-    // ridge-dominated element (header comment; NaN / inf end in the status test of either path)
-    const bool ridge = MR > 0 && ridge_dominated(eps2, M);
-    const bool any_ridge = __any(ridge);
-    [[maybe_unused]] bool ridge_ok = true;
     double d0 = (tb * gl - ta * gr) * idet;
     double d1 = (gr - gl) * idet;
 
-    // cold path's per-lane scratch (never touched by a wave that stays on the fast path)
-    [[maybe_unused]] double slowbuf[MR > 0 ? ChebSlow<M>::kSize : 1];
     if constexpr (MR == 0) {
       if (any_slow) {
         const double idx = rcp_newton(tb - ta);
@@ -465,16 +468,6 @@ __device__ __forceinline__ void enhance_small_body_cheb(const EnhanceArgs& p, co
 #pragma unroll
       for (int j = 1; j < MR; ++j) mm[MR - 1 + j] = fma(2.0, P[j], -mom[MR - 1 - j]);
 
-      // --- ridge-dominated elements: the wave also solves in the Legendre-bubble basis (cold) -----
-      if (any_ridge) {
-        using L = ChebSlow<M>;
-#pragma unroll
-        for (int d = 0; d < 2 * MR - 1; ++d) slowbuf[L::kMom + d] = mm[d];
-#pragma unroll
-        for (int i = 0; i < MR; ++i) slowbuf[L::kRhs + i] = rv[i];
-        ridge_ok = cheb_ridge_solve<M>(slowbuf, ta, tb, gl, gr, eps2);
-      }
-
       // --- S2 = m_{i+k} + m_{|i-k|} + 2 eps (N + C_z^T C_z),  rhs2 = r2 + 2 eps C_z^T d ----------
       double G[NT];
       if (any_slow) {
@@ -483,6 +476,16 @@ __device__ __forceinline__ void enhance_small_body_cheb(const EnhanceArgs& p, co
         for (int d = 0; d < 2 * MR - 1; ++d) slowbuf[L::kMom + d] = mm[d];
 #pragma unroll
         for (int i = 0; i < MR; ++i) slowbuf[L::kRhs + i] = rv[i];
+        // ridge-dominated lanes: the whole solve in the Legendre-bubble basis, result parked in kRes
+        const bool ridge = ridge_dominated(eps2, M);
+        double flag = 0.0;
+        if (__any(ridge)) {
+          const bool rok = cheb_ridge_solve<M>(slowbuf, ta, tb, gl, gr, eps2);
+          flag = ridge ? (rok ? 1.0 : -1.0) : 0.0;
+#pragma unroll
+          for (int i = 0; i < MR; ++i) slowbuf[L::kRhs + i] = rv[i];       // (transformed in place there)
+        }
+        slowbuf[L::kFlag] = flag;
         cheb_slow_build<M>(slowbuf, ta, tb, gl, gr, eps2);
 #pragma unroll
         for (int t = 0; t < NT; ++t) G[t] = slowbuf[L::kS + t];
@@ -635,21 +638,20 @@ __device__ __forceinline__ void enhance_small_body_cheb(const EnhanceArgs& p, co
           to_legendre();
         }
       }
-      if (any_ridge) {
-        // a ridge-dominated lane takes the cold path's result (the other lanes of the wave keep theirs)
-        if (ridge) {
-          ok = ridge_ok;
-          w0 = slowbuf[ChebSlow<M>::kRes];
-          w1 = slowbuf[ChebSlow<M>::kRes + 1];
-#pragma unroll
-          for (int j = 0; j < MR; ++j) w[j + 2] = slowbuf[ChebSlow<M>::kRes + 2 + j];
-        }
-      }
 #pragma unroll
       for (int j = 0; j < MR; ++j) ok = ok && (fabs(w[j + 2]) < 1.0e300);
       w[0] = w0;
       w[1] = w1;
       ok = ok && (fabs(w0) < 1.0e300) && (fabs(w1) < 1.0e300);
+      if (any_slow) {
+        // A ridge-dominated lane: its coefficients are the ones parked in slowbuf[kRes] and its status is
+        // that solve's; they OVERWRITE the lane's row at the store (below) instead of being selected into
+        // w[] here -- a select (or a branch with a join on w[]) costs every launch 39 vector instructions
+        // per wave (3 %, measured with SQ_INSTS_VALU).  The asm keeps this a branch.
+        asm volatile("" ::: "memory");
+        rflag = slowbuf[ChebSlow<M>::kFlag];
+        if (rflag != 0.0) ok = rflag > 0.0;
+      }
       if (!ok) st = LSSVR_ST_FALLBACK;
     }
 
@@ -680,6 +682,13 @@ __device__ __forceinline__ void enhance_small_body_cheb(const EnhanceArgs& p, co
       double* const Wrow = p.W + id * (p.ldw ? p.ldw : (int64_t)M);
 #pragma unroll
       for (int i = 0; i < M; ++i) Wrow[i] = w[i];
+      if constexpr (MR > 0) {
+        if (rflag > 0.0) {                     // ridge-dominated lane: the parked result (see above)
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int i = 0; i < M; ++i) Wrow[i] = slowbuf[ChebSlow<M>::kRes + i];
+        }
+      }
     }
 #endif   // LSSVR_DECOMP != 4
   }
@@ -693,6 +702,13 @@ __device__ __forceinline__ void enhance_small_body_cheb(const EnhanceArgs& p, co
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
   for (int i = 0; i < M; ++i) wt[lane * M + i] = w[i];
+  if constexpr (MR > 0) {
+    if (rflag > 0.0) {                         // ridge-dominated lane: the parked result (see above)
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < M; ++i) wt[lane * M + i] = slowbuf[ChebSlow<M>::kRes + i];
+    }
+  }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
   const int64_t base = ((int64_t)block * kBlock + (tid & ~63)) * M;

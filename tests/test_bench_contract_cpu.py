@@ -100,3 +100,56 @@ def test_config5_bench_line_contract():
     assert j["value"] >= 1.0e6
     t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["c5_M9_n16_ne1000008"]
     assert 0.9 <= t["hbm_bytes_per_launch"] / t["algorithmic_bytes_per_launch"] <= 1.25
+
+
+def test_round4_default_line_contract():
+    """Round 4: `roofline` prices the kernel the TIMED REGION launches with the region's own per-step time (the
+    round-3 line priced the enhancement-only kernel stamped elsewhere: 0.46 against 0.41), `value` is the median of
+    >= 10 brackets of exactly K steps, and BASELINE configs 4 and 5 ride along in the default line with their own
+    roofline and CPU baseline."""
+    j = _line("r04_bench_n1.json")
+    ne = j["config"]["elements_total"]
+    assert ne == 100008 and abs(j["value"] - ne / (j["ms_per_step"] * 1e-3)) <= 1e-6 * j["value"]
+    assert j["timed_brackets"] >= 10 and j["ms_per_step_min"] <= j["ms_per_step"] <= j["ms_per_step_max"]
+    assert j["ms_per_step_max"] <= 1.25 * j["ms_per_step_min"]
+    r = j["roofline"]
+    assert r["kernel"].startswith("step_small_kernel<M=9>") and r["bound"] == "fp64-valu"
+    assert abs(r["kernel_us_avg"] - j["ms_per_step"] * 1e3) <= 1e-9 * r["kernel_us_avg"]
+    flops = r["flops_per_element"] * r["elements_per_launch"]
+    assert abs(r["achieved"] - flops / (r["kernel_us_avg"] * 1e-6) / 1e12) <= 1e-9 * r["achieved"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-12 and r["peak"] == 78.6
+    eo = r["enhancement_only"]
+    assert eo["kernel"].startswith("enhance_small_kernel") and eo["kernel_us_in_sequence_avg"] <= 1.05 * r["kernel_us_avg"]
+    ex = r["executed"]
+    assert 0.0 < ex["issue_slot_frac"] <= 1.0 and "r04" in ex["source"]
+    assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["value"] > 0
+    for key, bound, unit in (("config4", "fp64-valu", "TFLOP/s"), ("config5", "hbm", "GB/s")):
+        c = j[key]
+        cr = c["roofline"]
+        assert cr["bound"] == bound and cr["unit"] == unit and abs(cr["frac"] - cr["achieved"] / cr["peak"]) <= 1e-12
+        assert abs(cr["kernel_us_avg"] - c["ms_per_step"] * 1e3) <= 1e-9 * cr["kernel_us_avg"]
+        assert abs(c["value"] - c["config"]["elements_total"] / (c["ms_per_step"] * 1e-3)) <= 1e-6 * c["value"]
+        assert c["timed_brackets"] >= 10 and c["value"] >= 1.0e6
+        cb = c["cpu_baseline"]
+        assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["wall_s"] < 60.0
+        assert c["accuracy"]["rel_l2_vs_60_digit_minimiser"] <= 1e-13
+        assert c["accuracy"]["rel_l2_bubble_vs_60_digit_minimiser"] <= 1e-13
+    assert "degree 32 / 64 points" in j["config4"]["cpu_baseline"]["sample"]
+    assert "Dual.py:43-44" in j["config5"]["cpu_baseline"]["sample"]
+    assert j["config5"]["roofline"]["bytes_per_element"] == 472
+
+
+def test_round4_multi_gpu_line_carries_roofline_and_cpu_baseline():
+    """The N > 1 line (rehearsed with two gloo ranks on one GPU: its rates mean nothing for xGMI) has the keys the
+    N = 1 line is judged on: aggregate roofline against N x the one-GPU peaks, HBM beside it, the CPU baseline."""
+    j = _line("r04_bench_gloo2_rehearsal.json")
+    n = j["n_gpus"]
+    assert n == 2 and j["timed_brackets"] >= 10
+    r = j["roofline"]
+    assert r["peak"] == n * 78.6 and abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-12
+    assert abs(r["kernel_us_avg"] - j["ms_per_step"] * 1e3) <= 1e-9 * r["kernel_us_avg"]
+    tot = j["config"]["elements_total"]
+    assert abs(r["achieved"] - r["flops_per_element"] * tot / (r["kernel_us_avg"] * 1e-6) / 1e12) <= 1e-9 * r["achieved"]
+    assert j["roofline_hbm"]["peak"] == n * 8000.0
+    c = j["cpu_baseline"]
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1

@@ -132,6 +132,15 @@ def test_bench_self_launches_its_ranks(dev):
             assert a["own_block_intact"] and a["bytes_per_element"] == nbytes
             assert a["bytes_received_per_rank_per_step"] == 100004 * nbytes
     assert out["weak_scaling"]["value"] > 0 and out["one_rank_same_workload"]["value"] > 0
+    # the N > 1 line is judged like the N = 1 line: aggregate roofline (all shards over the slowest rank's
+    # step, against N x the one-GPU peaks) and the CPU baseline timed by rank 0 in the same run
+    rf = out["roofline"]
+    assert rf["peak"] == 2 * 78.6 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0 < rf["frac"] < 1.5
+    assert abs(rf["kernel_us_avg"] - out["ms_per_step"] * 1e3) < 1e-6 * rf["kernel_us_avg"]
+    assert abs(rf["achieved"] - rf["flops_per_element"] * 200008 / (rf["kernel_us_avg"] * 1e-6) / 1e12) < 1e-9 * rf["achieved"]
+    assert out["roofline_hbm"]["peak"] == 2 * 8000.0 and 0 < out["roofline_hbm"]["frac"] < 1
+    assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["cores"] >= 1
+    assert out["timed_brackets"] >= 10 and out["ms_per_step_min"] <= out["ms_per_step"] <= out["ms_per_step_max"]
 
 
 def test_bench_single_rank_line(dev):
@@ -143,7 +152,22 @@ def test_bench_single_rank_line(dev):
     rf = out["roofline"]
     assert rf["bound"] == "fp64-valu" and 0 < rf["frac"] < 1.5 and rf["kernel_us_avg"] > 1
     assert abs(rf["achieved"] / rf["peak"] - rf["frac"]) < 1e-12
+    # the roofline prices the kernel the timed region launches with the region's own per-step time
+    assert rf["kernel"].startswith("step_small_kernel<M=9>")
+    assert abs(rf["kernel_us_avg"] - out["ms_per_step"] * 1e3) < 1e-6 * rf["kernel_us_avg"]
+    assert rf["enhancement_only"]["kernel_us_in_sequence_avg"] > 1
+    assert out["timed_brackets"] >= 10 and out["ms_per_step_min"] <= out["ms_per_step"] <= out["ms_per_step_max"]
     assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["value"] > 0
     assert out["ms_per_step"] <= out["host_wall_ms_per_step"] * 1.05
     assert out["accuracy"]["rel_l2_vs_float64_kkt_oracle"] < 1e-13
     assert out["config"]["fallback_elements"] == 0
+    # BASELINE configs 4 and 5 ride along in the default line (compact objects, same contract)
+    for key, bound in (("config4", "fp64-valu"), ("config5", "hbm")):
+        c = out[key]
+        assert "error" not in c, c
+        assert c["value"] >= 1.0e6 and c["timed_brackets"] >= 10
+        assert c["roofline"]["bound"] == bound and 0 < c["roofline"]["frac"] < 1.5
+        assert abs(c["roofline"]["kernel_us_avg"] - c["ms_per_step"] * 1e3) < 1e-6 * c["roofline"]["kernel_us_avg"]
+        assert c["cpu_baseline"]["kind"] == "port" and c["cpu_baseline"]["value"] > 0
+        assert c["accuracy"]["rel_l2_vs_60_digit_minimiser"] < 1e-13 and c["config"]["fallback_elements"] == 0
+    assert out["config4"]["config"]["elements_total"] == 100008 and out["config5"]["config"]["elements_total"] == 1000008
