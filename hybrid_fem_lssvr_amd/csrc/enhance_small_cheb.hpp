@@ -48,14 +48,14 @@ namespace lssvr {
 constexpr int kReseed = 64;   // in-kernel rhs: the (sin, cos) rotation is re-seeded every 64 points
 constexpr int kRefineMinM = 14; // near-square refinement of the lane kernel: instantiated from here up
 
-// MEASUREMENT AID (never defined in the shipped build; scripts/decompose_small.sh builds the variants):
-// LSSVR_DECOMP = 1 empty body (launch, wave ramp, nothing else), 2 the four loads of an element and
-// nothing else, 3 loads + all arithmetic but no store, 4 loads + the transposed store but no arithmetic,
-// 5 the full kernel with per-lane row stores instead of the transposed coalesced ones.
-// The differences attribute the kernel's time at BASELINE config 2.
-#ifndef LSSVR_DECOMP
-#define LSSVR_DECOMP 0
-#endif
+// MEASUREMENT HOOK: the body calls probe.mark(k) at its phase boundaries.  The shipped kernels pass NoProbe
+// (nothing is emitted); scripts/micro/lane_phases.hip instantiates the SAME body with a probe that stamps
+// s_memrealtime per wave: the per-phase timeline of DESIGN.md section 7.  (Round 3 carried five preprocessor
+// variants of the body in this header instead; their numbers are profiles/r03_decompose_small.txt.)
+struct NoProbe {
+  __device__ __forceinline__ void mark(int) const {}
+};
+enum LanePhase : int { kPhEntry = 0, kPhLoaded, kPhMoments, kPhSystem, kPhSolved, kPhStored, kPhCount };
 
 template <int M, int RHS>
 constexpr int kChebTilePerWave =
@@ -237,9 +237,9 @@ __device__ __attribute__((noinline)) bool cheb_ridge_solve(double* __restrict__ 
 // REFINE: the build with the near-square refinement loop (its own kernel, enhance_small_refine_kernel:
 // compiled into the main kernel the loop cost the NORMAL regime 15-65 % at M = 16..22 through register
 // allocation alone -- 61 -> 101 us at M = 20, n = 40 -- so launches with p.refine == 0 never see it).
-template <int M, int RHS, bool REFINE = false>
+template <int M, int RHS, bool REFINE = false, class Probe = NoProbe>
 __device__ __forceinline__ void enhance_small_body_cheb(const EnhanceArgs& p, const unsigned block,
-                                                        double* __restrict__ tile) {
+                                                        double* __restrict__ tile, const Probe probe = Probe{}) {
   constexpr int MR = M - 2;
   constexpr int TD = MR > 0 ? MR : 1;
   constexpr int NT = MR * (MR + 1) / 2;
@@ -253,15 +253,8 @@ __device__ __forceinline__ void enhance_small_body_cheb(const EnhanceArgs& p, co
   // verdict on the ridge-dominated solve parked in it (ChebSlow<M>::kFlag)
   [[maybe_unused]] double slowbuf[MR > 0 ? ChebSlow<M>::kSize : 1];
   [[maybe_unused]] double rflag = 0.0;
-#if LSSVR_DECOMP == 1
-  if (p.ne >= 0) return;
-#endif
-
-#if LSSVR_DECOMP == 5
-  const bool scattered = true;                 // (measurement: per-lane row stores instead of the LDS transposition)
-#else
+  probe.mark(kPhEntry);
   const bool scattered = p.elem_ids != nullptr || (p.ldw != 0 && p.ldw != M);
-#endif
   // Every lane runs the body (lanes past the end of the last wave on a duplicate of the last
   // element, their stores masked): tabulated inputs are loaded cooperatively by the wave.
   bool live = e < p.ne;
@@ -285,16 +278,8 @@ __device__ __forceinline__ void enhance_small_body_cheb(const EnhanceArgs& p, co
     const double gl = (eg == 0 && a == p.gxmin) ? p.bc_left : p.u[id];
     const double gr = (eg == p.ne_global - 1 && b == p.gxmax) ? p.bc_right : p.u[id + 1];
     const double inv_gamma = p.gamma_values ? rcp_newton(p.gamma_values[id]) : p.inv_gamma;
-#if LSSVR_DECOMP == 2
-    if (a + b + gl + gr == 1.2345e300 && p.status) p.status[id] = 1;      // (never: keeps the loads alive)
-    return;
-#endif
-#if LSSVR_DECOMP == 4
-#pragma unroll
-    for (int i = 0; i < M; ++i) w[i] = a + (double)i * gl + b * gr;
-    if (live && p.status) p.status[id] = st;
-#else
 
+    probe.mark(kPhLoaded);
     const DomainMap dm = map_params(a, b);
     const int n = p.n;
     const double step = dm.oldlen / (double)(n - 1);
@@ -461,6 +446,7 @@ __device__ __forceinline__ void enhance_small_body_cheb(const EnhanceArgs& p, co
         if (k1 == n) point(b, n - 1);
       }
       mom[0] = (double)n;
+      probe.mark(kPhMoments);
       // all moments m_0 .. m_{2MR-2}:  m_{MR-1+j} = 2 P_j - m_{MR-1-j}
       double mm[2 * TD - 1];
 #pragma unroll
@@ -518,6 +504,7 @@ __device__ __forceinline__ void enhance_small_body_cheb(const EnhanceArgs& p, co
         }
       }
 
+      probe.mark(kPhSystem);
       // --- LDL^T (lower, in place; unit L below the diagonal, diagonal holds 1/d_j).  No
       // square roots, no pre-scaling (elimination of an SPD matrix is invariant under symmetric
       // diagonal scaling up to rounding).  A zero / non-finite pivot turns into inf / NaN in
@@ -663,15 +650,7 @@ __device__ __forceinline__ void enhance_small_body_cheb(const EnhanceArgs& p, co
       w[1] = 0.5 * (gr - gl);
       if (live && p.fail_count) atomicAdd(p.fail_count, 1);
     }
-#if LSSVR_DECOMP == 3
-    {
-      double acc = 0.0;
-#pragma unroll
-      for (int i = 0; i < M; ++i) acc += w[i];
-      if (acc == 1.2345e300 && p.status) p.status[id] = st;              // (never: keeps the arithmetic alive)
-      return;
-    }
-#endif
+    probe.mark(kPhSolved);
     if (live && p.status) {
       if (p.ne * (int64_t)M <= kWriteThroughMaxDoubles)          // small launch: write-through, like W below
         __hip_atomic_store(&p.status[id], st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -690,7 +669,6 @@ __device__ __forceinline__ void enhance_small_body_cheb(const EnhanceArgs& p, co
         }
       }
     }
-#endif   // LSSVR_DECOMP != 4
   }
   if (scattered) return;
 
@@ -720,6 +698,7 @@ __device__ __forceinline__ void enhance_small_body_cheb(const EnhanceArgs& p, co
       const int64_t idx = base + (int64_t)i * 64 + lane;
       if (idx < total) __hip_atomic_store(&p.W[idx], wt[i * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    probe.mark(kPhStored);
     return;
   }
 #pragma unroll
@@ -728,6 +707,7 @@ __device__ __forceinline__ void enhance_small_body_cheb(const EnhanceArgs& p, co
     // write-once output: non-temporal stores leave less for the end-of-kernel L2 write-back
     if (idx < total) __builtin_nontemporal_store(wt[i * 64 + lane], &p.W[idx]);
   }
+  probe.mark(kPhStored);
 }
 
 }  // namespace lssvr

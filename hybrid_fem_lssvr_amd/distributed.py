@@ -113,20 +113,36 @@ def allgather_flat(out, src, rank, world, *, algo="collective", group=None):
 
 
 def allgather_rows(local, plan, rank, group=None, chunks=1, out=None, compute_chunk=None,
-                   algo="collective"):
-    """Stitch per-rank row blocks into the global array, on every rank.
+                   algo="collective", stats=None):
+    """Stitch per-rank row blocks into the global array, on every rank -- every block lands in ``out`` where
+    it belongs, with as few extra passes over HBM as the algorithm allows (round 3 staged every chunk and then
+    issued ``world`` copy kernels per chunk: each received byte crossed HBM twice more than needed):
+
+    * ``algo="pairs"``: point-to-point receives straight into ``out``'s row ranges (shards of any size, any
+      chunking): no staging buffer, no copy of received bytes;
+    * ``algo="collective"``, equal shards, one chunk: ``all_gather_into_tensor`` straight into ``out``;
+    * ``algo="collective"`` otherwise (chunked, or shard sizes differing by one): the backend's all-gather
+      needs one contiguous equal-sized destination, so the chunk is gathered into a staging buffer and moved
+      by ONE strided copy (equal shards) or ONE ``index_copy_`` (ragged) -- not ``world`` copies.
+
+    This rank's own rows: when ``compute_chunk`` produces them and no ``local`` buffer is given, they are
+    computed directly inside ``out`` (no copy at all); otherwise one copy per chunk.
 
     local: [max_size or size(rank), C] tensor (rows beyond ``plan.size(rank)`` ignored)
            -- or None when ``compute_chunk`` produces it piecewise.
     compute_chunk(r0, r1, dst): optional; fills ``dst`` (a [r1-r0, C] view of the local
            block) for local rows [r0, r1) on the current stream.  With ``chunks > 1`` the
            gather of chunk i overlaps the computation of chunk i+1 (CUDA tensors only).
-    algo:  "collective" or "pairs" (:func:`allgather_flat`).
+    stats: optional dict, filled with ``copy_calls`` / ``bytes_copied`` (device copies of row data issued
+           here), ``staged_bytes`` and ``collectives`` / ``p2p_ops`` -- what the tests count.
     Returns ``out`` [plan.ne, C].
     """
     world = plan.world
-    n_loc = plan.size(rank)
+    s0, s1 = plan.bounds(rank)
+    n_loc = s1 - s0
     pad = plan.max_size
+    if algo not in ALLGATHER_ALGOS:
+        raise ValueError(f"unknown all-gather algorithm {algo!r} (choose from {ALLGATHER_ALGOS})")
     if local is None and compute_chunk is None:
         raise ValueError("need local rows or a compute_chunk callback")
     ref = local if local is not None else out
@@ -134,20 +150,83 @@ def allgather_rows(local, plan, rank, group=None, chunks=1, out=None, compute_ch
         raise ValueError("pass `out` when rows are produced by compute_chunk")
     C = ref.shape[1]
     device, dtype = ref.device, ref.dtype
+    esize = torch.empty((), dtype=dtype).element_size()
     if out is None:
         out = torch.empty((plan.ne, C), dtype=dtype, device=device)
-    if local is None:
-        local = torch.empty((pad, C), dtype=dtype, device=device)
-    elif local.shape[0] < pad:
-        grown = torch.zeros((pad, C), dtype=dtype, device=device)
-        grown[:local.shape[0]] = local
-        local = grown
+    st = stats if stats is not None else {}
+    for key in ("copy_calls", "bytes_copied", "staged_bytes", "collectives", "p2p_ops"):
+        st.setdefault(key, 0)
+
+    def copied(rows):
+        st["copy_calls"] += 1
+        st["bytes_copied"] += int(rows) * C * esize
+
+    equal = plan.ne % world == 0
+    in_place = local is None                       # compute this rank's rows inside `out`
+    own = out[s0:s1] if in_place else local
     chunks = max(1, min(int(chunks), pad)) if pad > 0 else 1
     step = -(-pad // chunks) if pad > 0 else 0
-    stage = torch.empty((world, max(step, 1), C), dtype=dtype, device=device)
+    direct = algo == "pairs" or world == 1 or (equal and chunks == 1)
+    stage = send = None
+    if not direct:
+        stage = torch.empty((world, max(step, 1), C), dtype=dtype, device=device)
+        st["staged_bytes"] = stage.numel() * esize
+        if in_place or own.shape[0] < pad:
+            # the collective ships equal blocks: ragged shards send a zero-padded copy of each chunk
+            send = torch.zeros((max(step, 1), C), dtype=dtype, device=device)
     use_streams = device.type == "cuda"
     comm = torch.cuda.Stream(device=device) if use_streams else None
     main = torch.cuda.current_stream(device) if use_streams else None
+
+    def exchange(r0, r1):
+        lo, hi = min(r0, n_loc), min(r1, n_loc)        # this rank's rows of the chunk
+        if direct:
+            if not in_place and hi > lo:
+                out[s0 + lo:s0 + hi].copy_(own[lo:hi])
+                copied(hi - lo)
+            if world == 1:
+                return
+            if algo == "collective":                    # equal shards, one chunk: rank-major IS the global order
+                dist.all_gather_into_tensor(out.view(-1), out[s0:s1].reshape(-1), group=group)
+                st["collectives"] += 1
+                return
+            reqs = []
+            for off in range(1, world):
+                to, frm = (rank + off) % world, (rank - off) % world
+                f0, f1 = plan.bounds(frm)
+                flo, fhi = min(r0, f1 - f0), min(r1, f1 - f0)
+                if hi > lo:
+                    reqs.append(dist.P2POp(dist.isend, out[s0 + lo:s0 + hi], to, group=group))
+                if fhi > flo:
+                    reqs.append(dist.P2POp(dist.irecv, out[f0 + flo:f0 + fhi], frm, group=group))
+            st["p2p_ops"] += len(reqs)
+            if reqs:
+                for req in dist.batch_isend_irecv(reqs):
+                    req.wait()
+            return
+        # collective through the staging buffer: one gather, ONE move
+        nrow = r1 - r0
+        if send is not None:
+            src = send[:nrow]
+            if hi - lo < nrow:
+                src[max(hi - lo, 0):].zero_()
+            if hi > lo:
+                src[:hi - lo].copy_(own[lo:hi])
+                copied(hi - lo)
+        else:
+            src = own[r0:r1]
+        dst = stage[:, :nrow]
+        if not dst.is_contiguous():
+            dst = torch.empty((world, nrow, C), dtype=dtype, device=device)
+        dist.all_gather_into_tensor(dst.view(-1), src.reshape(-1), group=group)
+        st["collectives"] += 1
+        if equal:
+            out.view(world, pad, C)[:, r0:r1].copy_(dst)                 # one strided copy
+            copied(world * nrow)
+        else:
+            idx = _ragged_index(plan, r0, r1, nrow, device)
+            out.index_copy_(0, idx[0], dst.reshape(world * nrow, C).index_select(0, idx[1]))
+            copied(idx[0].numel())
 
     for ci in range(chunks):
         r0 = ci * step
@@ -157,50 +236,49 @@ def allgather_rows(local, plan, rank, group=None, chunks=1, out=None, compute_ch
         if compute_chunk is not None:
             lo, hi = min(r0, n_loc), min(r1, n_loc)
             if hi > lo:
-                compute_chunk(lo, hi, local[lo:hi])
-        src = local[r0:r1]
-        dst = stage[:, : r1 - r0]
+                compute_chunk(lo, hi, own[lo:hi])
         if use_streams:
             ready = torch.cuda.Event()
             ready.record(main)
             comm.wait_event(ready)
             with torch.cuda.stream(comm):
-                _gather_chunk(dst, src, rank, world, group, algo)
-                _scatter_rows(out, dst, plan, r0, r1)
-                stage.record_stream(comm)
+                exchange(r0, r1)
                 out.record_stream(comm)
+                if stage is not None:
+                    stage.record_stream(comm)
         else:
-            _gather_chunk(dst, src, rank, world, group, algo)
-            _scatter_rows(out, dst, plan, r0, r1)
+            exchange(r0, r1)
     if use_streams:
         main.wait_stream(comm)
     return out
 
 
-def _gather_chunk(dst, src, rank, world, group, algo="collective"):
-    if world == 1:
-        dst[0].copy_(src)
-        return
-    if dst.is_contiguous():
-        allgather_flat(dst.view(-1), src.contiguous().view(-1), rank, world, algo=algo, group=group)
-    else:
-        tmp = torch.empty((world,) + tuple(src.shape), dtype=src.dtype, device=src.device)
-        allgather_flat(tmp.view(-1), src.contiguous().view(-1), rank, world, algo=algo, group=group)
-        dst.copy_(tmp)
+_RAGGED_IDX = {}
 
 
-def _scatter_rows(out, staged, plan, r0, r1):
-    """staged[r, j] = row r0+j of rank r's block -> its global position."""
-    for r in range(plan.world):
-        s0, s1 = plan.bounds(r)
-        lo, hi = min(r0, s1 - s0), min(r1, s1 - s0)
-        if hi > lo:
-            out[s0 + lo:s0 + hi].copy_(staged[r, lo - r0:hi - r0])
+def _ragged_index(plan, r0, r1, nrow, device):
+    """(destination rows in the global array, source rows in the [world * nrow] staged chunk) of the rows
+    [r0, r1) of every rank's block, for shard sizes that differ by one; cached per plan / chunk / device."""
+    key = (plan.ne, plan.world, r0, r1, str(device))
+    hit = _RAGGED_IDX.get(key)
+    if hit is None:
+        dst, src = [], []
+        for r in range(plan.world):
+            f0, f1 = plan.bounds(r)
+            lo, hi = min(r0, f1 - f0), min(r1, f1 - f0)
+            if hi > lo:
+                dst.append(torch.arange(f0 + lo, f0 + hi))
+                src.append(torch.arange(r * nrow + lo - r0, r * nrow + hi - r0))
+        hit = (torch.cat(dst).to(device), torch.cat(src).to(device))
+        if len(_RAGGED_IDX) > 64:
+            _RAGGED_IDX.clear()
+        _RAGGED_IDX[key] = hit
+    return hit
 
 
 def enhance_sharded(x_local, u_local, plan, rank, M, gamma, n_colloc=12, *, global_domain,
                     rhs=None, bc=(0.0, 0.0), group=None, chunks=4, gather=True, out=None,
-                    algo="collective"):
+                    algo="collective", stats=None):
     """Rank-local enhancement of this rank's shard + (optionally) the stitched global W.
 
     x_local/u_local: float64 device tensors of the shard's nodes (``plan.node_slice(rank)``).
@@ -213,8 +291,6 @@ def enhance_sharded(x_local, u_local, plan, rank, M, gamma, n_colloc=12, *, glob
     if x_local.numel() != n_loc + 1:
         raise ValueError(f"rank {rank} owns {n_loc} elements, expected {n_loc + 1} nodes")
     dev = x_local.device
-    pad = plan.max_size
-    W_buf = torch.empty((pad, M), dtype=torch.float64, device=dev)
     status = torch.empty((n_loc,), dtype=torch.int32, device=dev)
     kw = {} if rhs is None else {"rhs": rhs}
 
@@ -224,16 +300,16 @@ def enhance_sharded(x_local, u_local, plan, rank, M, gamma, n_colloc=12, *, glob
                     out=dst, status=status[lo:hi], **kw)
 
     if not gather:
+        W_loc = torch.empty((n_loc, M), dtype=torch.float64, device=dev)
         if n_loc:
-            compute(0, n_loc, W_buf[:n_loc])
-        return W_buf[:n_loc], status, None
+            compute(0, n_loc, W_loc)
+        return W_loc, status, None
     if out is None:
         out = torch.empty((plan.ne, M), dtype=torch.float64, device=dev)
-    if pad > n_loc:
-        W_buf[n_loc:].zero_()      # the collective never ships uninitialised memory
-    Wg = allgather_rows(W_buf, plan, rank, group=group, chunks=chunks, out=out,
-                        compute_chunk=compute, algo=algo)
-    return W_buf[:n_loc], status, Wg
+    # the shard's rows are computed where they belong in the global array; the gather fills in the rest
+    Wg = allgather_rows(None, plan, rank, group=group, chunks=chunks, out=out,
+                        compute_chunk=compute, algo=algo, stats=stats)
+    return Wg[s0:s1], status, Wg
 
 
 # --------------------------------------------------------------------------
@@ -285,7 +361,7 @@ def solve_fem_sharded(x_ext, plan, rank, *, nquad=2, rhs=None, u0=0.0, u1=0.0, g
 
 
 def solve_sharded(x_ext, plan, rank, M, gamma, n_colloc=12, *, global_domain, nquad=2, rhs=None,
-                  bc=(0.0, 0.0), group=None, chunks=4, gather=True):
+                  bc=(0.0, 0.0), group=None, chunks=4, gather=True, algo="collective"):
     """Solve-then-enhance (Dual.py:171-174) on a sharded mesh: sharded P1 solve, rank-local
     enhancement, optional all-gather of W.  Returns (u_local, W_local, status, W_global|None)."""
     s0, _ = plan.bounds(rank)
@@ -293,5 +369,5 @@ def solve_sharded(x_ext, plan, rank, M, gamma, n_colloc=12, *, global_domain, nq
     u, _ = solve_fem_sharded(x_ext, plan, rank, nquad=nquad, rhs=rhs, u0=bc[0], u1=bc[1], group=group)
     Wl, st, Wg = enhance_sharded(x_ext[halo:], u, plan, rank, M, gamma, n_colloc,
                                  global_domain=global_domain, rhs=rhs, bc=bc, group=group,
-                                 chunks=chunks, gather=gather)
+                                 chunks=chunks, gather=gather, algo=algo)
     return u, Wl, st, Wg

@@ -77,7 +77,7 @@ def _stream(stream):
     return int(stream)
 
 
-_WORK = {}
+_WORK = {}                     # device index -> {"buf", "event", "stream"}: ONE shared scratch buffer per device
 _WORK_LOCK = threading.Lock()
 
 
@@ -88,35 +88,74 @@ def _torch_stream(handle, device):
     return torch.cuda.ExternalStream(int(handle), device=device)
 
 
-def workspace(lib, device, ne, M, n_colloc, solver, stream=None):
-    """Device scratch for ``lssvr_enhance_ws`` (``lssvr_enhance_work_bytes``): one buffer per
-    (device, stream), grown on demand.  Calls on ONE stream are ordered, so they may share it;
-    calls on different streams of a device, or from different host threads on different streams,
-    get different buffers (round 2 shared one buffer per device: two concurrent launches above
-    M = 22 raced on the moments between the two kernels).  A buffer that is replaced by a larger
-    one is handed back to the caching allocator only after ``record_stream`` on the stream that
-    may still be reading it.  None when no workspace is needed."""
-    nbytes = int(lib.lssvr_enhance_work_bytes(int(ne), int(M), int(n_colloc), int(solver)))
-    if nbytes <= 0:
-        return None
-    handle = _stream(stream)
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device(), handle)
-    with _WORK_LOCK:
-        buf = _WORK.get(key)
-        if buf is None or buf.numel() * 8 < nbytes:
-            if buf is not None:
-                buf.record_stream(_torch_stream(handle, device))
-            buf = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=device)
-            _WORK[key] = buf
-    return buf
+class workspace:
+    """Context manager around ONE launch that needs the scratch of ``lssvr_enhance_ws``
+    (``lssvr_enhance_work_bytes``; None inside the ``with`` when no workspace is needed).
+
+    One buffer per DEVICE, grown on demand, shared by every stream: a launch on another stream than the previous
+    user first waits (on the device, ``hipStreamWaitEvent``) for the event recorded after that user's launch, so
+    launches above M = 22 that go through this default workspace are serialised ACROSS streams (pass your own
+    ``work=`` buffers, as :class:`StepPlan` does, for concurrent streams).  Memory: 96-128 doubles per element of
+    the largest launch so far (0.8-1 GB per 1e6 elements), once per device -- round 3 kept one such buffer per
+    (device, stream handle) for the life of the process, and a destroyed-and-reused handle could alias another
+    stream's buffer.  The lock is held from hand-out to the recorded event, so host threads cannot
+    interleave between the two."""
+
+    def __init__(self, lib, device, ne, M, n_colloc, solver, stream=None):
+        self.nbytes = int(lib.lssvr_enhance_work_bytes(int(ne), int(M), int(n_colloc), int(solver)))
+        self.device, self.handle, self.locked = device, _stream(stream), False
+
+    def __enter__(self):
+        if self.nbytes <= 0:
+            return None
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        _WORK_LOCK.acquire()
+        self.locked = True
+        ent = _WORK.get(idx)
+        self.ts = _torch_stream(self.handle, self.device)
+        if ent is not None and ent["event"] is not None and ent["stream"] != self.handle:
+            self.ts.wait_event(ent["event"])            # the previous user's kernels are done before ours start
+        if ent is None or ent["buf"].numel() * 8 < self.nbytes:
+            # (a replaced buffer's last use is ordered before this stream's work by the wait above)
+            if ent is not None:
+                ent["buf"].record_stream(self.ts)
+            ent = {"buf": torch.empty((self.nbytes + 7) // 8, dtype=torch.float64, device=self.device), "event": None}
+            _WORK[idx] = ent
+        ent["stream"] = self.handle
+        self.ent = ent
+        return ent["buf"]
+
+    def __exit__(self, *exc):
+        if self.locked:
+            try:
+                ev = torch.cuda.Event()
+                ev.record(self.ts)
+                self.ent["event"] = ev
+            finally:
+                self.locked = False
+                _WORK_LOCK.release()
+        return False
 
 
 def release_workspaces():
-    """Drop every cached workspace (they are kept for the life of the process otherwise)."""
+    """Drop every cached workspace (one per device otherwise, for the life of the process).  The device is
+    synchronised first: no stream handle that may have been destroyed meanwhile is touched."""
     with _WORK_LOCK:
-        for (_, _, handle), buf in list(_WORK.items()):
-            buf.record_stream(_torch_stream(handle, buf.device))
+        if _WORK:
+            torch.cuda.synchronize()
         _WORK.clear()
+
+
+def _work_arg(work, lib, x, ne, M, n_colloc, solver, stream):
+    """(context manager yielding the workspace tensor or None) for the ``work=`` convention of the wrappers:
+    None = the shared per-device buffer, False = no workspace, a tensor = the caller's own."""
+    import contextlib
+    if work is None:
+        return workspace(lib, x.device, ne, M, n_colloc, solver, stream)
+    if work is False:
+        return contextlib.nullcontext(None)
+    _dev(work, "work")
+    return contextlib.nullcontext(work)
 
 
 def enhance(x, u, M, gamma, n_colloc=12, *, rhs=(POISSON_AMP, POISSON_OMEGA), rhs_values=None,
@@ -158,18 +197,13 @@ def enhance(x, u, M, gamma, n_colloc=12, *, rhs=(POISSON_AMP, POISSON_OMEGA), rh
         rhs_id, params = (RHS_ARRAY_PM if point_major else RHS_ARRAY), None
     else:
         rhs_id, params = RHS_SIN, _capi.rhs_params(*rhs)
-    if work is None:
-        work = workspace(lib, x.device, ne, M, n_colloc, solver, stream)
-    elif work is False:
-        work = None
-    else:
-        _dev(work, "work")
-    rc = lib.lssvr_enhance_ws(_ptr(x), _ptr(u), ne, int(elem_offset), int(ne_global),
-                              float(global_domain[0]), float(global_domain[1]),
-                              float(bc[0]), float(bc[1]), int(M), int(n_colloc), float(gamma),
-                              rhs_id, params, _ptr(rhs_values), int(solver),
-                              _ptr(out), _ptr(status), _ptr(fail_count),
-                              _ptr(work), 0 if work is None else work.numel() * 8, _stream(stream), None)
+    with _work_arg(work, lib, x, ne, M, n_colloc, solver, stream) as wk:
+        rc = lib.lssvr_enhance_ws(_ptr(x), _ptr(u), ne, int(elem_offset), int(ne_global),
+                                  float(global_domain[0]), float(global_domain[1]),
+                                  float(bc[0]), float(bc[1]), int(M), int(n_colloc), float(gamma),
+                                  rhs_id, params, _ptr(rhs_values), int(solver),
+                                  _ptr(out), _ptr(status), _ptr(fail_count),
+                                  _ptr(wk), 0 if wk is None else wk.numel() * 8, _stream(stream), None)
     _capi.check(rc, "lssvr_enhance_ws")
     return out, status
 
@@ -215,18 +249,13 @@ def enhance_subset(x, u, M, gamma, n_colloc, W, *, elem_ids=None, gamma_values=N
         rhs_id, params = (RHS_ARRAY_PM if point_major else RHS_ARRAY), None
     else:
         rhs_id, params = RHS_SIN, _capi.rhs_params(*rhs)
-    if work is None:
-        work = workspace(lib, x.device, nsub, M, n_colloc, SOLVER_PRIMAL, stream)
-    elif work is False:
-        work = None
-    else:
-        _dev(work, "work")
-    rc = lib.lssvr_enhance_subset_ws(_ptr(x), _ptr(u), ne, _ptr(elem_ids), int(nsub), int(elem_offset),
-                                     int(ne_global), float(global_domain[0]), float(global_domain[1]),
-                                     float(bc[0]), float(bc[1]), int(M), int(n_colloc), float(gamma),
-                                     _ptr(gamma_values), rhs_id, params, _ptr(rhs_values),
-                                     _ptr(W), int(W.shape[1]), _ptr(status), _ptr(fail_count),
-                                     _ptr(work), 0 if work is None else work.numel() * 8, _stream(stream))
+    with _work_arg(work, lib, x, nsub, M, n_colloc, SOLVER_PRIMAL, stream) as wk:
+        rc = lib.lssvr_enhance_subset_ws(_ptr(x), _ptr(u), ne, _ptr(elem_ids), int(nsub), int(elem_offset),
+                                         int(ne_global), float(global_domain[0]), float(global_domain[1]),
+                                         float(bc[0]), float(bc[1]), int(M), int(n_colloc), float(gamma),
+                                         _ptr(gamma_values), rhs_id, params, _ptr(rhs_values),
+                                         _ptr(W), int(W.shape[1]), _ptr(status), _ptr(fail_count),
+                                         _ptr(wk), 0 if wk is None else wk.numel() * 8, _stream(stream))
     _capi.check(rc, "lssvr_enhance_subset_ws")
     return W
 
@@ -313,10 +342,14 @@ def enhance_profiled(x, u, M, gamma, n_colloc=12, *, rhs=(POISSON_AMP, POISSON_O
         ne_global = elem_offset + ne
     out, status = _check_buffers(ne, M, n_colloc, x, out=out, status=status)
     ms = ctypes.c_float(0.0)
-    if work is None:
-        work = workspace(lib, x.device, ne, M, n_colloc, solver, stream)
-    elif work is False:
-        work = None
+    with _work_arg(work, lib, x, ne, M, n_colloc, solver, stream) as wk:
+        return _enhance_profiled(lib, x, u, ne, elem_offset, ne_global, global_domain, bc, M, n_colloc, gamma, rhs,
+                                 solver, out, status, wk, stream, repeats, ms)
+
+
+def _enhance_profiled(lib, x, u, ne, elem_offset, ne_global, global_domain, bc, M, n_colloc, gamma, rhs, solver,
+                      out, status, work, stream, repeats, ms):
+    import ctypes
     if repeats is not None:
         arr = (ctypes.c_float * int(repeats))()
         rc = lib.lssvr_enhance_ws_sequence(_ptr(x), _ptr(u), ne, int(elem_offset), int(ne_global),

@@ -93,15 +93,21 @@ def _to_dev(a, device):
 def _rhs_mode(rhs, x_dev, n_colloc, M=None):
     """Keyword arguments of ops.enhance for the right-hand side: ``rhs=(amp, omega)`` for the named
     f, else the callable (Dual.py:20 ``rhs_func``) tabulated on the host at np.linspace's points
-    (Dual.py:40) -- POINT-major (``t[k, e]``) for the lane-per-element kernels (M <= 22), which read
-    that layout at full HBM rate, element-major otherwise; the values are the same either way."""
+    (Dual.py:40).  The callable ALWAYS sees the element-major array ``x[e, k]`` -- points along the last
+    axis, as in the reference, where it receives the 1-D array of one element's n points (Dual.py:40-44): a
+    callable that returns a per-point vector of shape (n,), or otherwise relies on the last axis being the
+    points, broadcasts the same at every degree (up to M = 22 it used to see the transposed
+    array).  The TABLE is then handed over point-major (``t[k, e]``) for the lane-per-element kernels
+    (M <= 22), which read that layout at full HBM rate, element-major otherwise; same values either way."""
     if isinstance(rhs, SinRHS):
         return dict(rhs=(rhs.amp, rhs.omega))
     pm = M is not None and int(M) <= 22
-    xc = ops.colloc_points(x_dev, n_colloc, point_major=pm)    # np.linspace per element
+    xc = ops.colloc_points(x_dev, n_colloc)                    # np.linspace per element: [ne, n]
     f = np.asarray(rhs(xc.cpu().numpy()), dtype=np.float64)
     if f.shape != tuple(xc.shape):
         f = np.broadcast_to(f, tuple(xc.shape))
+    if pm:
+        f = np.ascontiguousarray(f.T)
     return dict(rhs_values=_to_dev(f, x_dev.device), point_major=pm)
 
 

@@ -73,6 +73,81 @@ def test_two_rank_gloo_stitch(ne, chunks, algo):
     assert abs(orc.clenshaw(1.0, Wref[0]) - np.cos(2 * nodes[1])) < 1e-12
 
 
+def _count_worker(rank, world, port, ne, C, chunks, algo, in_place, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from hybrid_fem_lssvr_amd.distributed import ShardPlan, allgather_rows
+        plan = ShardPlan(ne, world)
+        s0, s1 = plan.bounds(rank)
+
+        def compute(lo, hi, dst):
+            dst.copy_((torch.arange(s0 + lo, s0 + hi, dtype=torch.float64)[:, None] * 10.0
+                       + torch.arange(C, dtype=torch.float64)[None, :]))
+
+        stats = {}
+        if in_place:
+            out = torch.full((ne, C), -1.0, dtype=torch.float64)
+            Wg = allgather_rows(None, plan, rank, chunks=chunks, out=out, compute_chunk=compute, algo=algo,
+                                stats=stats)
+        else:
+            local = torch.zeros((plan.size(rank), C), dtype=torch.float64)
+            compute(0, s1 - s0, local)
+            Wg = allgather_rows(local, plan, rank, chunks=chunks, algo=algo, stats=stats)
+        q.put((rank, Wg.numpy(), stats))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,ne,chunks,algo,in_place", [
+    (2, 12, 1, "collective", True), (2, 12, 1, "collective", False), (2, 12, 3, "collective", True),
+    (3, 11, 1, "collective", True), (3, 11, 2, "collective", False),
+    (2, 12, 1, "pairs", True), (3, 11, 3, "pairs", True), (3, 11, 2, "pairs", False)])
+def test_allgather_rows_lands_blocks_in_place(world, ne, chunks, algo, in_place):
+    """Round-3 review: the receive side staged every chunk and then issued `world` copy kernels per chunk.
+    Now: the direct exchange and the unchunked equal-shard all-gather receive straight into the global
+    array (no staging, no copy of received bytes; zero copies at all when the shard is computed in place),
+    and the staged collective moves a chunk with ONE copy.  Counted through the `stats` hook."""
+    C = 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_count_worker, args=(r, world, port, ne, C, chunks, algo, in_place, q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r, W, st = q.get(timeout=120)
+        got[r] = (W, st)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    want = np.arange(ne, dtype=np.float64)[:, None] * 10.0 + np.arange(C, dtype=np.float64)[None, :]
+    from hybrid_fem_lssvr_amd.distributed import ShardPlan
+    plan = ShardPlan(ne, world)
+    for r in range(world):
+        W, st = got[r]
+        assert np.array_equal(W, want), (r, st)
+        own_bytes = plan.size(r) * C * 8
+        equal = ne % world == 0
+        nchunks = min(chunks, plan.max_size)
+        if algo == "pairs":
+            assert st["staged_bytes"] == 0 and st["collectives"] == 0 and st["p2p_ops"] > 0
+            assert st["bytes_copied"] == (0 if in_place else own_bytes)          # never a received byte
+            assert st["copy_calls"] <= (0 if in_place else nchunks)
+        elif equal and chunks == 1:
+            assert st["staged_bytes"] == 0 and st["collectives"] == 1
+            assert st["bytes_copied"] == (0 if in_place else own_bytes)
+        else:
+            assert st["collectives"] == nchunks and st["staged_bytes"] > 0
+            # ONE move per chunk on the receive side (round 3: `world` per chunk) + at most one staging copy of
+            # this rank's own rows per chunk (ragged or computed-in-place shards)
+            assert st["copy_calls"] <= 2 * nchunks
+            assert st["bytes_copied"] <= ne * C * 8 + own_bytes
+
+
 def test_single_rank_allgather_is_identity():
     from hybrid_fem_lssvr_amd.distributed import ShardPlan, allgather_rows
     plan = ShardPlan(9, 1)

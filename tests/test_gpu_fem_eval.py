@@ -476,3 +476,29 @@ def test_facade_callable_rhs_is_tabulated_in_the_kernels_layout(dev, M, n):
     W_em, _ = ops.enhance(x, u, M, 1e4, n, global_domain=(-1.0, 1.0), rhs_values=f_em)
     torch.cuda.synchronize()
     assert torch.equal(W_em, tabd.W)
+
+
+@pytest.mark.parametrize("M,n", [(9, 16), (22, 16), (33, 64)])
+def test_facade_callable_rhs_sees_points_on_the_last_axis(dev, M, n):
+    """the reference hands ``rhs_func`` the 1-D array of ONE element's n points (Dual.py:40-44), so a
+    callable may return a per-point vector of shape (n,) or otherwise rely on the last axis being the points.
+    The facade evaluates it on the element-major ``x[e, k]`` at every degree (and transposes the TABLE for the
+    lane kernels): a constant-in-e, varying-in-k right-hand side broadcasts the same below and above M = 22 --
+    also on a mesh with ne == n, where a transposed evaluation would go unnoticed by the shape check."""
+    import hybrid_fem_lssvr_amd as pkg
+    from hybrid_fem_lssvr_amd import ops
+    profile = np.cos(np.arange(n) * 0.37) + 2.0                       # f_k: depends on the POINT index only
+
+    def per_point(x):
+        assert x.shape[-1] == n                                       # points along the last axis, always
+        return profile                                                # shape (n,): broadcasts over elements
+
+    for ne in (n, 40):
+        nodes = np.linspace(-1, 1, ne + 1)
+        values = orc.fem_p1_solve(nodes)
+        got = pkg.enhance_elements(nodes, values, M, 1e4, n_colloc=n, rhs=per_point)
+        x, u = _t(nodes, dev), _t(values, dev)
+        table = _t(np.broadcast_to(profile, (ne, n)).copy(), dev)     # element-major [ne, n]
+        want, st = ops.enhance(x, u, M, 1e4, n, global_domain=(-1.0, 1.0), rhs_values=table)
+        assert got.n_fallback == 0 and int(st.sum()) == 0
+        assert orc.rel_l2_coef(got.W.cpu().numpy(), want.cpu().numpy()).max() <= 1e-14

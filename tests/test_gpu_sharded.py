@@ -20,7 +20,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, ne, M, n, q, backend="gloo"):
+def _worker(rank, world, port, ne, M, n, q, backend="gloo", algo="collective"):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -37,15 +37,15 @@ def _worker(rank, world, port, ne, M, n, q, backend="gloo"):
         lo = s0 - 1 if s0 > 0 else s0
         x_ext = torch.as_tensor(nodes[lo:s1 + 1].copy(), device=dev)
         u, Wl, st, Wg = solve_sharded(x_ext, plan, rank, M, 1e4, n, global_domain=(-1.0, 1.0),
-                                      chunks=2)
+                                      chunks=2, algo=algo)
         torch.cuda.synchronize()
         q.put((rank, u.cpu().numpy(), Wg.cpu().numpy(), int(st.sum().item())))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [1, 2, 3])
-def test_sharded_solve_matches_single_rank(dev, world):
+@pytest.mark.parametrize("world,algo", [(1, "collective"), (2, "collective"), (3, "collective"), (2, "pairs"), (3, "pairs")])
+def test_sharded_solve_matches_single_rank(dev, world, algo):
     import hybrid_fem_lssvr_amd as pkg
     ne, M, n = 10001, 9, 16
     ref = pkg.FEMLSSVRPrimalSolver(ne + 1, lssvr_M=M, lssvr_gamma=1e4, n_colloc=n, fem_solver="flux")
@@ -54,7 +54,7 @@ def test_sharded_solve_matches_single_rank(dev, world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, ne, M, n, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ne, M, n, q, "gloo", algo)) for r in range(world)]
     for p in procs:
         p.start()
     got = {}
@@ -78,17 +78,19 @@ def test_sharded_solve_matches_single_rank(dev, world):
     assert np.array_equal(got[0][1], got[world - 1][1])
 
 
-def test_sharded_pipeline_over_rccl_single_rank(dev):
+@pytest.mark.parametrize("algo", ["collective", "pairs"])
+def test_sharded_pipeline_over_rccl_single_rank(dev, algo):
     """The same pipeline with backend "nccl" (= RCCL) and ONE rank: what a one-GPU box can
     exercise of the production backend -- communicator bring-up, the 24-byte all-gather of the
-    flux aggregates and the chunk-overlapped all-gather of W on a side stream."""
+    flux aggregates and the chunk-overlapped stitch of W on a side stream, with the backend's
+    all-gather and with the direct all-pairs form (`algo="pairs"`, driven through enhance_sharded)."""
     import hybrid_fem_lssvr_amd as pkg
     ne, M, n = 10001, 9, 16
     ref = pkg.FEMLSSVRPrimalSolver(ne + 1, lssvr_M=M, lssvr_gamma=1e4, n_colloc=n, fem_solver="flux")
     ref.solve()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_worker, args=(0, 1, _free_port(), ne, M, n, q, "nccl"))
+    p = ctx.Process(target=_worker, args=(0, 1, _free_port(), ne, M, n, q, "nccl", algo))
     p.start()
     r, u, Wg, nbad = q.get(timeout=300)
     p.join(120)
