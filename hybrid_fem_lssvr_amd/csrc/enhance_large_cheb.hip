@@ -141,7 +141,7 @@ __device__ __forceinline__ void solve_four(const EnhanceArgs& p, const int lane,
     const double hh = 0.5 * dm.oldlen;
     const double inv_scl2 = hh * hh;
     const double eps2 = (2.0 * inv_gamma) * (inv_scl2 * inv_scl2);
-    if (ridge_dominated(eps2, M)) live = false;       // solved by moments_kernel (ridge_wave_solve)
+    if (ridge_dominated(eps2, M)) live = false;       // solved by ridge_fixup_kernel
 
     // ---- boundary rows to first order (enhance_small_cheb.hpp); exact recurrence when the wave
     // holds an element beyond the first-order range
@@ -597,43 +597,40 @@ __global__ __launch_bounds__(kMomBlock, 2) void moments_kernel(EnhanceArgs p, do
                            __HIP_MEMORY_SCOPE_SYSTEM);
     }
   });
-  // ---- ridge-dominated elements (coarse elements with a small gamma; none on a BASELINE mesh): the wave
-  // solves them here, one at a time, in the Legendre-bubble basis, and the solve kernels skip them.
-  // Everything the test needs is RECOMPUTED from memory behind an opaque thread index, so that nothing
-  // stays live across the accumulation loop for it (kept live, id / h / the flag cost the loop 33 spills).
-  {
-    unsigned tx = threadIdx.x;
-    asm volatile("" : "+v"(tx));
-    const int64_t e2 = (int64_t)blockIdx.x * kMomBlock + tx;
-    bool valid = e2 < p.ne;
-    int64_t id2 = valid ? e2 : p.ne - 1;
-    if (p.elem_ids) {
-      id2 = p.elem_ids[id2];
-      if (id2 < 0 || id2 >= p.ne_mesh) {     // (counted by the solve kernel)
-        id2 = 0;
-        valid = false;
-      }
+}
+
+// ---- ridge-dominated elements (coarse elements with a small gamma; none on a BASELINE mesh): the solve kernels skip
+// them (lssvr_device.hpp::ridge_dominated) and this kernel, the LAST of the sequence, solves them in the
+// Legendre-bubble basis from their workspace rows (ridge_wave_solve): one lane tests one element, a wave solves its
+// elements one at a time.  On an ordinary mesh it reads 16 B per element and exits (~2 us of the sequence).
+__global__ __launch_bounds__(256) void ridge_fixup_kernel(EnhanceArgs p, const double* __restrict__ ws) {
+  __shared__ double rtile[4 * 1216];
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  bool valid = e < p.ne;
+  int64_t id = valid ? e : p.ne - 1;
+  if (p.elem_ids) {
+    id = p.elem_ids[id];
+    if (id < 0 || id >= p.ne_mesh) {       // (counted by the solve kernel)
+      id = 0;
+      valid = false;
     }
-    const double h2 = 0.5 * (p.x[id2 + 1] - p.x[id2]);
-    const double is2 = h2 * h2;
-    const double inv_gamma = p.gamma_values ? rcp_newton(p.gamma_values[id2]) : p.inv_gamma;
-    const double eps2 = (2.0 * inv_gamma) * (is2 * is2);               // the solve kernels' expression
-    unsigned long long rmask = __ballot(valid && ridge_dominated(eps2, p.M));
-    if (rmask) {
-      __atomic_thread_fence(__ATOMIC_SEQ_CST);         // the wave's workspace rows are written
-      const int ln = tx & 63;
-      double* const tile = mtile + (tx >> 6) * (64 * 33);
-      const int64_t w0 = e2 - ln;                      // the wave's first element
-      while (rmask) {
-        const int t = __builtin_ctzll(rmask);
-        rmask &= rmask - 1;
-        const unsigned long long idt =
-            __builtin_bit_cast(unsigned long long, readlane_f64(__builtin_bit_cast(double, (unsigned long long)id2), t));
-        const int64_t idm = (int64_t)idt;
-        ridge_wave_solve(p.W + idm * (p.ldw ? p.ldw : (int64_t)p.M), p.status ? p.status + idm : nullptr,
-                         p.fail_count, p.M, ws + (w0 + t) * kWsStride, tile, ln, readlane_f64(eps2, t));
-      }
-    }
+  }
+  const double h2 = 0.5 * (p.x[id + 1] - p.x[id]);
+  const double is2 = h2 * h2;
+  const double inv_gamma = p.gamma_values ? rcp_newton(p.gamma_values[id]) : p.inv_gamma;
+  const double eps2 = (2.0 * inv_gamma) * (is2 * is2);                 // the solve kernels' expression
+  unsigned long long rmask = __ballot(valid && ridge_dominated(eps2, p.M));
+  if (!rmask) return;
+  const int lane = threadIdx.x & 63;
+  double* const tile = rtile + (threadIdx.x >> 6) * 1216;
+  const int64_t w0 = e - lane;                       // the wave's first element
+  while (rmask) {
+    const int t = __builtin_ctzll(rmask);
+    rmask &= rmask - 1;
+    const int64_t idm = (int64_t)__builtin_bit_cast(
+        unsigned long long, readlane_f64(__builtin_bit_cast(double, (unsigned long long)id), t));
+    ridge_wave_solve(p.W + idm * (p.ldw ? p.ldw : (int64_t)p.M), p.status ? p.status + idm : nullptr,
+                     p.fail_count, p.M, ws + (w0 + t) * kWsStride, tile, lane, readlane_f64(eps2, t));
   }
 }
 
@@ -832,6 +829,9 @@ hipError_t enhance_large_split(const EnhanceArgs& a, void* work, hipStream_t s, 
   hipError_t e = sine ? go(moments_kernel<LSSVR_RHS_SIN>, g1, t1, ev0, nullptr, a, ws)
                       : go(moments_kernel<LSSVR_RHS_ARRAY>, g1, t1, ev0, nullptr, a, ws);
   if (e != hipSuccess) return e;
+  // ridge-dominated elements, from the finished workspace rows and BEFORE a refinement pass overwrites their
+  // right-hand sides; the solve kernels below leave those elements alone
+  if ((e = go(ridge_fixup_kernel, gr, tr, nullptr, nullptr, a, cws)) != hipSuccess) return e;
   if (steps == 0 && enhance_parity_applies(a.M, a.n)) return launch_solve4_parity(a, cws, s, ev1);
   if (steps == 0) return go(solve4_kernel<0>, g2, t2, nullptr, ev1, a, cws, (double*)nullptr, nxcd);
   EnhanceArgs quiet = a;           // failures are counted once, by the last pass

@@ -186,7 +186,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void solve4_parity_kernel(EnhanceAr
     const double hh = 0.5 * dm.oldlen;
     const double inv_scl2 = hh * hh;
     const double eps2 = (2.0 * inv_gamma) * (inv_scl2 * inv_scl2);
-    if (ridge_dominated(eps2, M)) live = false;       // solved by moments_kernel (ridge_wave_solve)
+    if (ridge_dominated(eps2, M)) live = false;       // solved by ridge_fixup_kernel (enhance_large_cheb.hip)
 
     // ---- boundary rows to first order (enhance_small_cheb.hpp); exact recurrence when the wave
     // holds an element beyond the first-order range
