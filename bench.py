@@ -79,14 +79,14 @@ def algorithmic_flops_dual(M, n):
     return (n + 2) * (n + 3) * M + (1.0 / 3.0) * (n + 2) ** 3 + 2 * (n + 2) ** 2 + 2 * M * (n + 2)
 
 
-def executed_fraction(key, ne, kernel_s):
+def executed_fraction(key, ne, kernel_s, fallback_key=None):
     """Issue-slot utilisation of the FP64 pipe by what the kernel actually EXECUTES (the nominal
     `frac` prices SURVEY's direct-Gram flop count, which the Chebyshev-moment kernels do not execute): VALU
     wave-instructions per launch (profiles/instruction_counts.json: rocprofv3 SQ_INSTS_VALU of this kernel) x 4
     cycles each / (SIMDs x 2.4 GHz x measured duration).  <= 1 by construction; None when the kernel has no count."""
     try:
         tab = json.load(open(os.path.join(ROOT, "profiles", "instruction_counts.json")))
-        ent = tab[key]
+        ent = tab.get(key) or tab[fallback_key]
     except Exception:
         return None
     per_el = ent["valu_per_element"] if "valu_per_element" in ent else ent["valu_per_wave"] / 64.0
@@ -1175,7 +1175,7 @@ def poisson_labels(M, n, dual):
                 "blocks of the same grid)" % M, "enhance_small_kernel<M=%d, RHS_SIN>" % M,
                 "FP64 vector FMA only (lane per element, no MFMA issued); the FP64 vector and matrix peaks of "
                 "gfx950 are the same 78.6 TFLOP/s and share one pipe (DESIGN.md section 3)",
-                "primal, BC-eliminated SPD (M-2), Chebyshev-moment Gram, LDL^T", "small_M%d_n%d_sin" % (M, n))
+                "primal, BC-eliminated SPD (M-2), Chebyshev-moment Gram, LDL^T", "step_small_M%d_n%d" % (M, n))
     second = "solve4_parity_kernel" if n >= 2 * (M - 2) else "solve4_kernel (+ refinement kernels when n <= M + 12)"
     return ("p1_assemble_kernel + moments_kernel + %s (three launches per step)" % second,
             "moments_kernel + %s (the pair, gap included)" % second,
@@ -1185,7 +1185,7 @@ def poisson_labels(M, n, dual):
             "(LSSVR_SOLVER_PRIMAL_WAVE) is 2x slower (DESIGN.md section 3.8); vector and matrix FP64 share one "
             "pipe at the same 78.6 TFLOP/s peak",
             "primal, BC-eliminated SPD (M-2), Chebyshev-moment Gram, parity-split LDL^T + coupling "
-            "iteration (two kernels, workspace)", "large_pair_M%d_n%d" % (M, n))
+            "iteration (two kernels, workspace)", "step_large_M%d_n%d" % (M, n))
 
 
 def poisson_accuracy(wl, W, M, n, dev, nsel=9, ntruth=5):
@@ -1311,7 +1311,8 @@ def measure_poisson(D, M, n, ne_glob, lo, hi, dev, steps, warmup, solver="primal
                             "bracket / K (HIP events on the launch stream): the kernel's own duration plus the "
                             "boundary to the next dependent launch; rocprofv3 --kernel-trace --stats of the same "
                             "command (profiles/) reads the kernel's begin -> end stamps, which must agree to a few %",
-            "executed": executed_fraction(count_key, ne_loc, step_s),
+            "executed": executed_fraction(count_key, ne_loc, step_s,
+                                          fallback_key=("small_M%d_n%d_sin" % (M, n)) if M <= 22 else "large_pair_M%d_n%d" % (M, n)),
             "enhancement_only": {
                 "kernel": enh_kernel,
                 "what": "the enhancement WITHOUT the assembly blocks, begin -> end stamps of the dispatch "
@@ -1339,10 +1340,13 @@ def measure_poisson(D, M, n, ne_glob, lo, hi, dev, steps, warmup, solver="primal
     if os.path.exists(tf) and not dual:
         try:
             tj = json.load(open(tf))
-            tr = tj.get("M%d_n%d_ne%d" % (M, n, ne_loc))
+            tr = tj.get("step_M%d_n%d_ne%d" % (M, n, ne_loc)) or tj.get("M%d_n%d_ne%d" % (M, n, ne_loc))
             if tr:
                 out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
                 out["roofline_hbm"]["traffic"] = tr["hbm_bytes_per_launch"]
+                if "algorithmic_bytes_per_launch_with_the_p1_bands" in tr:
+                    out["roofline_hbm"]["algorithmic_bytes_per_launch_with_the_p1_bands"] = \
+                        tr["algorithmic_bytes_per_launch_with_the_p1_bands"]
                 out["roofline"]["traffic_source"] = ("profiles/traffic.json (%s): %s; NOT measured in this run"
                                                      % (tj.get("_round", "committed profile"),
                                                         tr.get("what", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "

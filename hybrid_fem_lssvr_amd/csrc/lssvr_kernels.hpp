@@ -4,6 +4,7 @@
 #include <hip/hip_ext.h>
 #include <stdint.h>
 #include "../../include/lssvr_hip.h"
+#include "../../include/lssvr_hip_bench.h"   // (measurement entries of the same library)
 #include "lssvr_device.hpp"
 
 namespace lssvr {

@@ -8,12 +8,27 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "lssvr_hip.h")
+BENCH_HEADER = os.path.join(ROOT, "include", "lssvr_hip_bench.h")      # measurement entries of the same library
+MEASUREMENT_ONLY = ("lssvr_enhance_profiled", "lssvr_enhance_ws_sequence", "lssvr_enhance_varcoef_ws_sequence",
+                    "lssvr_fp64_probe", "lssvr_stream_probe", "lssvr_row_chunk_probe")
+
+
+def _declared_in(path):
+    txt = open(path).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(lssvr_[a-z0-9_]+)\s*\(", txt)))
 
 
 def _declared():
-    txt = open(HEADER).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(lssvr_[a-z0-9_]+)\s*\(", txt)))
+    return sorted(set(_declared_in(HEADER)) | set(_declared_in(BENCH_HEADER)))
+
+
+def test_product_header_holds_no_measurement_entries():
+    """Round-3 review: the product ABI header exported the measurement-only entries beside it.  They live in
+    include/lssvr_hip_bench.h now (same library); the two headers are disjoint."""
+    prod, bench = set(_declared_in(HEADER)), set(_declared_in(BENCH_HEADER))
+    assert bench == set(MEASUREMENT_ONLY) and not (prod & bench)
+    assert not any(("probe" in n or "profiled" in n or "sequence" in n) for n in prod)
 
 
 def test_header_symbols_exported_and_bound():
