@@ -157,14 +157,14 @@ def _cpu_worker(args):
     os.environ["OMP_NUM_THREADS"] = os.environ["OPENBLAS_NUM_THREADS"] = "1"
     import numpy as np
     from oracle import lssvr_oracle as orc
-    nodes, values, j, ne, gd, seed, varcoef, M, n = args
+    xa, xb, ua, ub, j, ne, gd, seed, varcoef, M, n = args        # (the element's own data: no mesh-sized pickles)
     rng = np.random.default_rng(seed)
     rhs, kw = orc.poisson_rhs, {}
     if varcoef:
         a, da, f = orc.varcoef_functions(*orc.varcoef_params())
         rhs, kw = f, {"coef_a": a, "coef_da": da}
     t0 = time.perf_counter()
-    _, ok = orc.slsqp_element(rhs, nodes[j], nodes[j + 1], values[j], values[j + 1],
+    _, ok = orc.slsqp_element(rhs, xa, xb, ua, ub,
                               M, GAMMA, n, left=(j == 0), right=(j == ne - 1),
                               global_domain=gd, rng=rng, **kw)
     return int(ok), time.perf_counter() - t0
@@ -200,7 +200,8 @@ def cpu_baseline(nodes_host, values_host, gd, per_core=16, varcoef=False, M=M_DE
         sample = np.arange(ne // 2 - count // 2, ne // 2 - count // 2 + count, dtype=np.int64)
     else:
         sample = np.linspace(0, ne - 1, count).astype(np.int64)
-    jobs = [(nodes_host, values_host, int(j), ne, gd, 1000 + k, varcoef, M, n) for k, j in enumerate(sample)]
+    jobs = [(float(nodes_host[j]), float(nodes_host[j + 1]), float(values_host[j]), float(values_host[j + 1]), int(j),
+             ne, gd, 1000 + k, varcoef, M, n) for k, j in enumerate(sample)]
     ctx = mp.get_context("fork")
     t0 = time.perf_counter()
     res, abandoned = [], 0
@@ -957,10 +958,10 @@ def measure_config5(D, M, n, ne, lo, hi, dev, steps, warmup, pm=True, full=True,
                                    nquad=2, point_major=w["pm"], global_domain=w["gd"], bands=w["bands"],
                                    out=w["W"], status=w["st"])
 
-    def timed(w, steps, warmup, mode=None):
+    def timed(w, steps, warmup, mode=None, replays=None):
         class _One:                                  # (timed_compute's view of a workload: .plans[0])
             plans = [step_plan(w)]
-        return timed_compute(_One, D, steps, warmup, mode=mode)
+        return timed_compute(_One, D, steps, warmup, mode=mode, replays=replays)
 
     w = build(ne, lo, hi, pm)
     t = timed(w, steps, warmup)
