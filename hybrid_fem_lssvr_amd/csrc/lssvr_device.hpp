@@ -309,7 +309,10 @@ __host__ __device__ constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j
 __host__ __device__ constexpr double ridge_gamma_scl4(int M) {
   return (M <= 12) ? 3.0e-4 : (M <= 17) ? 1.0e-4 : 3.0e-5;
 }
-__host__ __device__ constexpr double ridge_eps2_threshold(int M) { return 2.0 / ridge_gamma_scl4(M); }
+// (every branch a compile-time constant: with a run-time M the division would be executed per wave)
+__host__ __device__ constexpr double ridge_eps2_threshold(int M) {
+  return (M <= 12) ? 2.0 / ridge_gamma_scl4(12) : (M <= 17) ? 2.0 / ridge_gamma_scl4(17) : 2.0 / ridge_gamma_scl4(33);
+}
 // (inf / NaN -- gamma = 0, a degenerate element -- are not "ridge": they end in the status test)
 __device__ __forceinline__ bool ridge_dominated(double eps2, int M) {
   return eps2 > ridge_eps2_threshold(M) && eps2 < 1.0e300;
