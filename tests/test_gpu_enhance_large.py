@@ -367,3 +367,35 @@ def test_moment_solver_needs_workspace(dev):
     W, st = _enhance(dev, nodes, values, 9, 1e4, 16, global_domain=(-1.0, 1.0), solver=ops.SOLVER_PRIMAL_MOMENT)
     Wd, _ = _enhance(dev, nodes, values, 9, 1e4, 16, global_domain=(-1.0, 1.0))
     assert np.all(st == 0) and orc.rel_l2_coef(W, Wd).max() <= 1e-12
+
+
+def test_default_workspace_is_handed_between_streams_in_event_order(dev):
+    """the default workspace above M = 22 is ONE buffer per device (not one per stream handle for the
+    life of the process).  Launches on different streams that go through it are ordered by the event recorded
+    after the previous user's launch: interleaved launches on two streams with DIFFERENT inputs must each return
+    their own result (a race on the moments between the kernels of a launch would mix them), the cache holds one
+    entry, and release_workspaces() empties it."""
+    import torch
+    from hybrid_fem_lssvr_amd import ops
+    M, n, ne = 33, 64, 3000
+    nodes = np.linspace(-1.0, 1.0, ne + 1)
+    xa = _t(nodes, dev)
+    ua = _t(np.sin(np.pi * nodes), dev)
+    ub = _t(np.cos(1.7 * nodes), dev)
+    ref_a, _ = ops.enhance(xa, ua, M, 1e4, n, global_domain=(-1.0, 1.0))
+    ref_b, _ = ops.enhance(xa, ub, M, 1e4, n, global_domain=(-1.0, 1.0))
+    torch.cuda.synchronize()
+    ref_a, ref_b = ref_a.clone(), ref_b.clone()
+    sa, sb = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    outs = []
+    for rep in range(6):                       # alternate streams; nothing synchronises the host in between
+        for s, u in ((sa, ua), (sb, ub)):
+            with torch.cuda.stream(s):
+                W, st = ops.enhance(xa, u, M, 1e4, n, global_domain=(-1.0, 1.0))
+                outs.append((W, u is ua))
+    torch.cuda.synchronize()
+    for W, is_a in outs:
+        assert torch.equal(W, ref_a if is_a else ref_b)
+    assert len(ops._WORK) == 1
+    ops.release_workspaces()
+    assert len(ops._WORK) == 0

@@ -75,3 +75,24 @@ def test_solver_surface_and_loud_failure_without_gpu():
             s.solve()
         with pytest.raises(RuntimeError, match="no CPU fallback"):
             pkg.lssvr_primal(pkg.poisson_rhs, [-1, 0], 0.0, 0.0, 5, 1e4)
+
+
+def test_bench_cpu_baseline_sample_and_budget():
+    """bench.py's CPU baseline (the reference's per-element SLSQP loop, oracle restatement): one job per element
+    carrying only that element's data, finished elements / wall time, a central sample for degree 32, and jobs still
+    running at the budget are abandoned and NOT counted."""
+    import importlib
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    bench = importlib.import_module("bench")        # (importable by name: its pool pickles the worker function)
+    nodes, values, gd = bench.wide_mesh(2400)
+    assert abs((nodes[1] - nodes[0]) - 1.0 / 12.0) < 1e-12 and values[0] == 0.0 and values[-1] == 0.0
+    r = bench.cpu_baseline(nodes, values, gd, per_core=1)
+    assert r["kind"] == "port" and r["cores"] >= 1 and r["value"] > 0 and r["wall_s"] < 60
+    assert "evenly spaced" in r["sample"] and "converged" in r["sample"]
+    # an impossible budget: nothing finishes, nothing is counted, the line says so
+    r0 = bench.cpu_baseline(nodes, values, gd, per_core=1, M=33, n=64, central=True, budget_s=0.05)
+    assert r0["value"] == 0.0 and "abandoned" in r0["sample"] and "nearest the origin" in r0["sample"]
