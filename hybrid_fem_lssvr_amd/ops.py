@@ -372,6 +372,16 @@ def _enhance_profiled(lib, x, u, ne, elem_offset, ne_global, global_domain, bc, 
     return ms.value * 1e-3
 
 
+def _bind(lib, name, args):
+    """(bound foreign function, arguments pre-converted to the ctypes of its signature): a plan is launched many
+    times, and converting ~20 Python values per call is a third of the host's ~7 us per launch of an ~8 us step."""
+    import ctypes
+    argtypes = _capi.SIGNATURES[name][1]
+    conv = tuple(a if (a is None or isinstance(a, (ctypes.Array, ctypes._SimpleCData, ctypes._Pointer))) else tp(a)
+                 for tp, a in zip(argtypes, args))
+    return getattr(lib, name), conv
+
+
 class StepPlan:
     """One step of the hot path (element-local P1 assembly + per-element enhancement of
     the same resident mesh shard) bound once, launched many times: the argument tuple of
@@ -412,6 +422,7 @@ class StepPlan:
                       int(M), int(n_colloc), float(gamma), self._keep[2], int(nquad),
                       _ptr(self.bands["diag"]), _ptr(self.bands["off"]), _ptr(self.bands["load"]),
                       _ptr(self.W), _ptr(self.status), _ptr(fail_count))
+        self._step, self._cargs = _bind(self.lib, "lssvr_step", self._args)
 
         if self._work is not None:
             self._asm_args = (_ptr(x), ne, int(nquad), RHS_SIN, self._keep[2], None, None,
@@ -430,7 +441,7 @@ class StepPlan:
             if rc >= 0:
                 rc = self.lib.lssvr_enhance_ws(*self._enh_args, st, None)
         else:
-            rc = self.lib.lssvr_step(*self._args, st)
+            rc = self._step(*self._cargs, st)
         if rc < 0:
             _capi.check(rc, "lssvr_step")
         return self.W, self.status
@@ -554,9 +565,10 @@ class StepPlanVarcoef:
                       _ptr(rhs_quad), _ptr(a_quad),
                       _ptr(self.bands["diag"]), _ptr(self.bands["off"]), _ptr(self.bands["load"]),
                       _ptr(self.W), _ptr(self.status), _ptr(fail_count))
+        self._step, self._cargs = _bind(self.lib, "lssvr_step_varcoef", self._args)
 
     def launch(self, stream=None):
-        rc = self.lib.lssvr_step_varcoef(*self._args, _stream(stream))
+        rc = self._step(*self._cargs, _stream(stream))
         if rc < 0:
             _capi.check(rc, "lssvr_step_varcoef")
         return self.W, self.status
