@@ -49,6 +49,18 @@ __global__ __launch_bounds__(kBlock) void plain_kernel(EnhanceArgs p) {
   enhance_small_body_cheb<9, LSSVR_RHS_SIN>(p, blockIdx.x, tile);
 }
 
+// ONE-WAVE WORKGROUPS (the round-3 review's first suggestion): the same body, 64 threads per workgroup.  The body
+// indexes elements as block * kBlock + tid, so workgroup b works on a view of the arrays shifted by 64 (b & 3)
+// elements with block index b >> 2: the same elements, the same arithmetic, 1 563 workgroups of one wave.
+__global__ __launch_bounds__(64) void plain64_kernel(EnhanceArgs p) {
+  __shared__ double tile[kChebTilePerWave<9, LSSVR_RHS_SIN>];
+  const int64_t off = 64 * (int64_t)(blockIdx.x & 3);
+  if (off + (int64_t)(blockIdx.x >> 2) * kBlock >= p.ne) return;
+  p.x += off; p.u += off; p.W += off * 9; p.status += off;
+  p.ne -= off; p.ne_mesh -= off; p.elem_offset += off;
+  enhance_small_body_cheb<9, LSSVR_RHS_SIN>(p, blockIdx.x >> 2, tile);
+}
+
 static double med(std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; }
 static double pct(std::vector<double> v, double q) { std::sort(v.begin(), v.end()); return v[(size_t)(q * (v.size() - 1))]; }
 
@@ -85,6 +97,14 @@ int main(int argc, char** argv) {
     return ge;
   };
   hipGraphExec_t gp = graph_of(false), gs = graph_of(true);
+  hipGraphExec_t g64;
+  {
+    hipGraph_t g;
+    hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+    for (int i = 0; i < K; ++i) hipLaunchKernelGGL(plain64_kernel, dim3(4 * blocks), dim3(64), 0, s, a);
+    hipStreamEndCapture(s, &g);
+    hipGraphInstantiate(&g64, g, nullptr, nullptr, 0);
+  }
   for (int i = 0; i < 300; ++i) hipGraphLaunch(gp, s);        // steady state (~50 ms)
   hipStreamSynchronize(s);
   auto time_graph = [&](hipGraphExec_t g) {
@@ -98,6 +118,18 @@ int main(int argc, char** argv) {
   printf("ne = %ld, %u workgroups of %d threads, K = %d launches per replay\n", ne, blocks, kBlock, K);
   printf("graph-replayed launch period, shipped body      : %.2f us\n", time_graph(gp));
   printf("graph-replayed launch period, body with stamps  : %.2f us\n", time_graph(gs));
+  {
+    std::vector<double> w256(ne * M), w64(ne * M);
+    hipGraphLaunch(gp, s); hipStreamSynchronize(s);
+    hipMemcpy(w256.data(), dW, ne * M * 8, hipMemcpyDeviceToHost);
+    hipMemset(dW, 0, ne * M * 8);
+    for (int i = 0; i < 50; ++i) hipGraphLaunch(g64, s);
+    hipStreamSynchronize(s);
+    const double t64 = time_graph(g64);
+    hipMemcpy(w64.data(), dW, ne * M * 8, hipMemcpyDeviceToHost);
+    printf("graph-replayed launch period, ONE-WAVE workgroups (%u x 64 threads): %.2f us   (256-thread form again: %.2f us; results %s)\n",
+           4 * blocks, t64, time_graph(gp), w256 == w64 ? "bit-equal" : "DIFFER");
+  }
   hipGraphLaunch(gs, s); hipStreamSynchronize(s);
   std::vector<unsigned long long> st((size_t)K * waves * kSlots);
   hipMemcpy(st.data(), dstamp, st.size() * 8, hipMemcpyDeviceToHost);
