@@ -463,13 +463,15 @@ __device__ __forceinline__ void enhance_small_body_cheb(const EnhanceArgs& p, co
 #pragma unroll
         for (int i = 0; i < MR; ++i) slowbuf[L::kRhs + i] = rv[i];
         // ridge-dominated lanes: the whole solve in the Legendre-bubble basis, result parked in kRes
-        const bool ridge = ridge_dominated(eps2, M);
         double flag = 0.0;
-        if (__any(ridge)) {
-          const bool rok = cheb_ridge_solve<M>(slowbuf, ta, tb, gl, gr, eps2);
-          flag = ridge ? (rok ? 1.0 : -1.0) : 0.0;
+        if constexpr (M >= kRidgeMinM) {
+          const bool ridge = ridge_dominated(eps2, M);
+          if (__any(ridge)) {
+            const bool rok = cheb_ridge_solve<M>(slowbuf, ta, tb, gl, gr, eps2);
+            flag = ridge ? (rok ? 1.0 : -1.0) : 0.0;
 #pragma unroll
-          for (int i = 0; i < MR; ++i) slowbuf[L::kRhs + i] = rv[i];       // (transformed in place there)
+            for (int i = 0; i < MR; ++i) slowbuf[L::kRhs + i] = rv[i];     // (transformed in place there)
+          }
         }
         slowbuf[L::kFlag] = flag;
         cheb_slow_build<M>(slowbuf, ta, tb, gl, gr, eps2);

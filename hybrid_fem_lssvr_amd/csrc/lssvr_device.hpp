@@ -313,9 +313,14 @@ __host__ __device__ constexpr double ridge_gamma_scl4(int M) {
 __host__ __device__ constexpr double ridge_eps2_threshold(int M) {
   return (M <= 12) ? 2.0 / ridge_gamma_scl4(12) : (M <= 17) ? 2.0 / ridge_gamma_scl4(17) : 2.0 / ridge_gamma_scl4(33);
 }
-// (inf / NaN -- gamma = 0, a degenerate element -- are not "ridge": they end in the status test)
+// (inf / NaN -- gamma = 0, a degenerate element -- are not "ridge": they end in the status test.)
+// M <= 4 never takes the ridge form: with at most two bubble coefficients Y is DIAGONAL (T_0 = rho_0 / 3,
+// T_1 = rho_1 / 15), the two bases differ by a diagonal scaling and the Chebyshev-basis solve is as well
+// conditioned as the other (measured 2e-16 at gamma scl^4 = 1e-12).  (The instantiation cheb_ridge_solve<4> also
+// aborted with a memory-aperture violation on the MI355X for a reason its ISA does not show; it is not compiled.)
+constexpr int kRidgeMinM = 5;
 __device__ __forceinline__ bool ridge_dominated(double eps2, int M) {
-  return eps2 > ridge_eps2_threshold(M) && eps2 < 1.0e300;
+  return M >= kRidgeMinM && eps2 > ridge_eps2_threshold(M) && eps2 < 1.0e300;
 }
 
 }  // namespace lssvr

@@ -306,7 +306,7 @@ def solve_ridge_kernel(s):
 
 def solve_kernel_dispatch(s):
     """What the Poisson kernels do per element: the ridge form below the threshold, else the moment form."""
-    if s.M > 2 and s.gamma_t < ridge_gamma_scl4(s.M):
+    if s.M >= 5 and s.gamma_t < ridge_gamma_scl4(s.M):          # (kRidgeMinM: Y is diagonal up to M = 4)
         return solve_ridge_kernel(s)
     return solve_cheb_kernel(s)
 

@@ -512,12 +512,12 @@ def _ridge_dominated(nodes, M, gamma):
     h = np.diff(nodes)
     thr = 3.0e-4 if M <= 12 else (1.0e-4 if M <= 17 else 3.0e-5)
     g4 = np.asarray(gamma, dtype=np.float64) * (2.0 / h) ** 4
-    return (M > 2) & (g4 < thr)
+    return (M >= 5) & (g4 < thr)          # (M <= 4: Y is diagonal, the moment form needs no help; kRidgeMinM)
 
 
 # gamma scl^4 of the sweep x (M, n): the verdict's table of round 3 (Chebyshev-moment form 2.6e-13 at M = 9 ..
 # 3e-11 at M = 22 / 33 where the float64 KKT solve holds 1e-15) and its two decades towards the crossover.
-RIDGE_SWEEP = [(M, n, g4) for (M, n) in [(5, 5), (9, 16), (14, 28), (22, 44), (33, 64)]
+RIDGE_SWEEP = [(M, n, g4) for (M, n) in [(3, 4), (4, 6), (5, 5), (9, 16), (14, 28), (22, 44), (33, 64)]
                for g4 in (1e-3, 1e-6, 1e-9, 1e-12)]
 
 
@@ -542,7 +542,8 @@ def test_ridge_dominated_sweep(dev, note, M, n, g4):
     values = np.sin(np.pi * nodes) + 0.01 * rng.standard_normal(ne + 1)
     gd = (nodes[0], nodes[-1])
     ridge = _ridge_dominated(nodes, M, gamma)
-    assert ridge.all() == (g4 < 1e-4) and ridge.any() == (g4 < 1e-4)      # 1e-3: the moment form, below: the ridge form
+    expect = (g4 < 1e-4) and M >= 5           # 1e-3 (and M <= 4 always): the moment form, below: the ridge form
+    assert ridge.all() == expect and ridge.any() == expect
     x, u = _t(nodes, dev), _t(values, dev)
     sel = [0, 1, 63, 64, 127, 128, ne - 1]
     tr = cf.truth_all(nodes, values, M, gamma, n, orc.poisson_rhs, gd, sel)
