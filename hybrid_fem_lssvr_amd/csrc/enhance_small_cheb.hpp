@@ -46,6 +46,7 @@
 namespace lssvr {
 
 constexpr int kReseed = 64;   // in-kernel rhs: the (sin, cos) rotation is re-seeded every 64 points
+constexpr int kPairMaxM = 12;   // in-kernel rhs: two collocation points per loop iteration up to here
 constexpr int kRefineMinM = 14; // near-square refinement of the lane kernel: instantiated from here up
 
 // MEASUREMENT HOOK: the body calls probe.mark(k) at its phase boundaries.  The shipped kernels pass NoProbe
@@ -55,7 +56,7 @@ constexpr int kRefineMinM = 14; // near-square refinement of the lane kernel: in
 struct NoProbe {
   __device__ __forceinline__ void mark(int) const {}
 };
-enum LanePhase : int { kPhEntry = 0, kPhLoaded, kPhMoments, kPhSystem, kPhSolved, kPhStored, kPhCount };
+enum LanePhase : int { kPhEntry = 0, kPhLoaded, kPhSeeded, kPhMoments, kPhSystem, kPhSolved, kPhStored, kPhCount };
 
 template <int M, int RHS>
 constexpr int kChebTilePerWave =
@@ -335,6 +336,7 @@ __device__ __forceinline__ void enhance_small_body_cheb(const EnhanceArgs& p, co
         kappa = -2.0 * (p.rhs_amp * inv_scl2);
       }
       [[maybe_unused]] const double fscale = -2.0 * inv_scl2;
+      probe.mark(kPhSeeded);
       // Tabulated rhs ([element][point]): the wave loads kStageK points of its 64 rows at a time
       // with consecutive lanes on consecutive doubles into LDS at pitch kStageK + 1 (conflict-free
       // when every lane then reads its own row); a lane walking its own row would touch 64 cache
@@ -442,8 +444,68 @@ __device__ __forceinline__ void enhance_small_body_cheb(const EnhanceArgs& p, co
         // h < 1e-320, where scl = 2/h overflows and the element ends in the linear fallback whatever
         // x_k is); the last point is peeled so that the loop carries no select
         const int kl = min(k1, n - 1);
-        for (int k = k0; k < kl; ++k) point((double)k * step + a, k);
-        if (k1 == n) point(b, n - 1);
+        int k = k0;
+        if constexpr (RHS == LSSVR_RHS_SIN && M <= kPairMaxM) {
+          // TWO points per iteration, their dependent chains (abscissa -> t -> T_2 .. T_{MR-1}, 11 links of
+          // 8.3 cycles at M = 9) side by side in one basic block: a wave issues in order, so with one point per
+          // iteration every link of the chain stalled it (347 cycles per point for a lone wave, 301 with two on
+          // the SIMD, against 45 instructions x 4.5).  No per-point branch in here: the wave qualifies when
+          // |delta| < 1e-7 is guaranteed a priori -- |delta_k| <= eps |omega| (3 n step + 3 max|x|) by the
+          // roundings of linspace / omega x_k / theta_0 / dtheta (eps = 2^-53), bounded below with 1e-15 |omega|
+          // max(|a|, |b|, h) -- so for such waves the per-point test of `point` is never true and the two forms
+          // perform the SAME operations in the SAME order: results are bit-equal.
+          const double xmax = fmax(fmax(fabs(a), fabs(b)), fabs(dm.oldlen));
+          const bool tame = fabs(p.rhs_omega) * xmax * 1.0e-15 < 1.0e-7;
+          if (!__any(!tame)) {
+            // points k (inside the element) and k + 1 (abscissa xB: the next linspace point, or b itself for the
+            // last one -- np.linspace's endpoint, as in `point(b, n - 1)`)
+            // (indices carried as doubles: exact, and no int -> double conversion in the loop)
+            auto pair = [&](const double kd, const double xB) {
+              const double jd = kd - (double)k0;
+              const double xA = kd * step + a;
+              const double tA = dm.off + dm.scl * xA;       // mapdomain, two roundings
+              const double tB = dm.off + dm.scl * xB;
+              const double argA = p.rhs_omega * xA;
+              const double argB = p.rhs_omega * xB;
+              const double dA = fma(-jd, dth, argA - th0);
+              const double dB = fma(-(jd + 1.0), dth, argB - th0);
+              const double phiA = fma(rc, dA, rs);
+              const double rs1 = fma(rs, cd, rc * sd);
+              const double rc1 = fma(rc, cd, -(rs * sd));
+              const double phiB = fma(rc1, dB, rs1);
+              rs = fma(rs1, cd, rc1 * sd);
+              rc = fma(rc1, cd, -(rs1 * sd));
+              double TA[TD], TB[TD];
+              TA[0] = TB[0] = 1.0;
+              if constexpr (MR > 1) {
+                TA[1] = tA;
+                TB[1] = tB;
+              }
+              const double ttA = tA + tA, ttB = tB + tB;
+#pragma unroll
+              for (int d = 2; d < MR; ++d) {
+                TA[d] = fma(ttA, TA[d - 1], -TA[d - 2]);
+                TB[d] = fma(ttB, TB[d - 1], -TB[d - 2]);
+              }
+              rv[0] = (rv[0] + phiA) + phiB;
+#pragma unroll
+              for (int d = 1; d < MR; ++d) {
+                mom[d] = (mom[d] + TA[d]) + TB[d];
+                P[d] = fma(TB[MR - 1], TB[d], fma(TA[MR - 1], TA[d], P[d]));
+                rv[d] = fma(TB[d], phiB, fma(TA[d], phiA, rv[d]));
+              }
+            };
+            double kd = (double)k0;
+            // (four points per iteration: 164 registers, the same phase time -- not kept)
+            for (; k + 2 <= kl; k += 2, kd += 2.0) pair(kd, (kd + 1.0) * step + a);
+            if (k + 1 == kl && k1 == n) {                  // an even number of points: the last two as a pair as well
+              pair(kd, b);
+              k = n;
+            }
+          }
+        }
+        for (; k < kl; ++k) point((double)k * step + a, k);
+        if (k1 == n && k < n) point(b, n - 1);
       }
       mom[0] = (double)n;
       probe.mark(kPhMoments);

@@ -27,6 +27,7 @@ __global__ __launch_bounds__(64) void k(double* out, long long* cyc, int iters, 
   }
   double x = 1.0 + 1e-9 * l, y = 1e-12 * (l + 1);
   const double s = __builtin_bit_cast(double, __builtin_amdgcn_readfirstlane((int)(__builtin_bit_cast(long long, sval) >> 32)) * 4294967296ll);
+  int it2 = 0;
   const long long t0 = __builtin_amdgcn_s_memtime();
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -42,6 +43,30 @@ __global__ __launch_bounds__(64) void k(double* out, long long* cyc, int iters, 
       if constexpr (KIND == 7) asm volatile("v_fma_f64 %0, %0, %0, %0" : "+v"(a));                                   // 1 register
       if constexpr (KIND == 8) asm volatile("v_fmac_f64_e32 %0, %1, %2" : "+v"(a) : "v"(x), "v"(y));                 // VOP2 accumulate
       if constexpr (KIND == 9) asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(a) : "v"(x), "v"(y), "v"(r[q & 7]));   // 3 reads + separate dst
+      if constexpr (KIND == 11) {                                                                                      // opcodes alternate: fma, add
+        if (q & 1) asm volatile("v_add_f64 %0, %0, %1" : "+v"(a) : "v"(x));
+        else asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(a) : "v"(x), "v"(y));
+      }
+      if constexpr (KIND == 12) {                                                                                      // fma, mul
+        if (q & 1) asm volatile("v_mul_f64 %0, %1, %2" : "=v"(a) : "v"(x), "v"(y));
+        else asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(a) : "v"(x), "v"(y));
+      }
+      if constexpr (KIND == 13) {                                                                                      // the lane loop's mix: 4 fmac/fma : 2 add : 1 mul
+        const int m = q % 7;
+        if (m == 2 || m == 5) asm volatile("v_add_f64 %0, %0, %1" : "+v"(a) : "v"(x));
+        else if (m == 6) asm volatile("v_mul_f64 %0, %1, %2" : "=v"(a) : "v"(x), "v"(y));
+        else asm volatile("v_fmac_f64_e32 %0, %1, %2" : "+v"(a) : "v"(x), "v"(y));
+      }
+      if constexpr (KIND == 14) {                                                                                      // the same mix with every add / mul written as an FMA
+        const int m = q % 7;
+        if (m == 2 || m == 5) asm volatile("v_fma_f64 %0, %1, 1.0, %0" : "+v"(a) : "v"(x));
+        else if (m == 6) asm volatile("v_fma_f64 %0, %1, %2, 0" : "=v"(a) : "v"(x), "v"(y));
+        else asm volatile("v_fmac_f64_e32 %0, %1, %2" : "+v"(a) : "v"(x), "v"(y));
+      }
+      if constexpr (KIND == 15) {                                                                                      // FP64 stream with a scalar instruction after every 8th
+        asm volatile("v_fmac_f64_e32 %0, %1, %2" : "+v"(a) : "v"(x), "v"(y));
+        if ((q & 7) == 7) asm volatile("s_add_i32 %0, %0, 1" : "+s"(it2));
+      }
       if constexpr (KIND == 10) {                                                                                      // 32-bit FMA for scale
         float& f = reinterpret_cast<float*>(&a)[0];
         asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(f) : "v"(reinterpret_cast<float*>(&x)[0]), "v"(reinterpret_cast<float*>(&y)[0]));
@@ -52,7 +77,7 @@ __global__ __launch_bounds__(64) void k(double* out, long long* cyc, int iters, 
   double sum = 0.0;
 #pragma unroll
   for (int i = 0; i < 8; ++i) sum += acc[i];
-  out[blockIdx.x * 64 + l] = sum + pad[(l * 7) & 63];
+  out[blockIdx.x * 64 + l] = sum + pad[(l * 7 + it2) & 63];
   if (l == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
@@ -105,6 +130,7 @@ int main() {
   printf("# %s, %d CUs, runtime clock %.2f GHz; one round of resident waves, %d-instruction body\n", prop.name, cus,
          prop.clockRate * 1e-6, kBody);
   const int iters = 3000;
+  for (int w = 0; w < 3; ++w) run<7, 20 * 1024>("(warm-up)", 2, cus, iters);
   sweep<0>("v_fma_f64 d += x*y   (3 VGPR pairs, x y fixed)", cus, iters);
   sweep<1>("v_fma_f64 d += r_i*r_j (3 VGPR pairs, Gram-like)", cus, iters);
   sweep<9>("v_fma_f64 d = x*y + c (3 VGPR pairs + separate dst)", cus, iters);
@@ -116,5 +142,10 @@ int main() {
   sweep<5>("v_mul_f64 d = x*y", cus, iters);
   sweep<6>("v_add_f64 d += x", cus, iters);
   sweep<10>("v_fma_f32 d += x*y", cus, iters);
+  sweep<11>("alternating v_fma_f64 / v_add_f64", cus, iters);
+  sweep<12>("alternating v_fma_f64 / v_mul_f64", cus, iters);
+  sweep<13>("lane-loop mix: 4 v_fmac : 2 v_add : 1 v_mul", cus, iters);
+  sweep<14>("the same mix, add and mul written as v_fma_f64", cus, iters);
+  sweep<15>("v_fmac_f64 with an s_add_i32 after every 8th", cus, iters);
   return 0;
 }

@@ -156,7 +156,7 @@ int main(int argc, char** argv) {
   }
   printf("launch %d of the replay, %ld waves (times in us):\n", l, waves);
   printf("  wave start after the launch's first wave : median %.2f  p90 %.2f  max %.2f\n", med(start), pct(start, 0.9), pct(start, 1.0));
-  const char* names[kPhCount] = {"", "entry -> inputs loaded (s_load + 4 global loads)", "collocation loop (16 points: moments, rhs)",
+  const char* names[kPhCount] = {"", "entry -> inputs loaded (s_load + 4 global loads)", "element set-up (map, boundary data, rhs seeds)", "collocation loop (16 points: moments, rhs)",
                                  "system built from the moments", "LDL^T + substitutions + v = Y z", "LDS transposition + stores issued"};
   for (int k = 1; k < kPhCount; ++k) printf("  %-52s: median %.2f  p10 %.2f  p90 %.2f\n", names[k], med(dur[k]), pct(dur[k], 0.1), pct(dur[k], 0.9));
   printf("  wave end after the launch's first wave   : median %.2f  p90 %.2f  max %.2f\n", med(endt), pct(endt, 0.9), pct(endt, 1.0));
@@ -195,6 +195,15 @@ int main(int argc, char** argv) {
     std::vector<double> d, lp;
     for (long w = 0; w < waves; ++w) if (cnt[key[w]] == c) { d.push_back(endt[w] - start[w]); lp.push_back(dur[kPhMoments][w]); }
     if (!d.empty()) printf("  waves on a SIMD with %d wave(s): %zu, lifetime median %.2f us, collocation loop median %.2f us\n", c, d.size(), med(d), med(lp));
+    if (!d.empty()) {
+      printf("    phases (us):");
+      for (int k = 1; k < kPhCount; ++k) {
+        std::vector<double> ph;
+        for (long w = 0; w < waves; ++w) if (cnt[key[w]] == c) ph.push_back(dur[k][w]);
+        printf(" %.2f", med(ph));
+      }
+      printf("\n");
+    }
   }
   return 0;
 }
