@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <vector>
 
+#include <cstring>
 #include "lssvr_hip.h"
 
 #define HIP_OK(x)                                                                  \
@@ -89,6 +90,20 @@ int main() {
   HIP_OK(hipMemcpyAsync(uh.data(), u, (ne + 1) * sizeof(double), hipMemcpyDeviceToHost, stream));
   HIP_OK(hipStreamSynchronize(stream));
 
+  // the same enhancement as a BOUND step (lssvr_step_plan_*: assembly + enhancement in one launch, arguments
+  // validated once): W2 must equal W bit for bit
+  double* W2 = dev_alloc<double>(ne * M);
+  lssvr_step_plan* plan = nullptr;
+  LSSVR_OK_OR_DIE(lssvr_step_plan_create(&plan, x, u, ne, 0, ne, lo, hi, 0.0, 0.0, M, n_colloc, gamma, rhs, 2, diag,
+                                         off, load, W2, status, nullptr));
+  for (int rep = 0; rep < 3; ++rep) LSSVR_OK_OR_DIE(lssvr_step_plan_launch(plan, stream));
+  std::vector<double> w1(ne * M), w2(ne * M);
+  HIP_OK(hipMemcpyAsync(w1.data(), W, ne * M * sizeof(double), hipMemcpyDeviceToHost, stream));
+  HIP_OK(hipMemcpyAsync(w2.data(), W2, ne * M * sizeof(double), hipMemcpyDeviceToHost, stream));
+  HIP_OK(hipStreamSynchronize(stream));
+  LSSVR_OK_OR_DIE(lssvr_step_plan_destroy(plan));
+  const bool plan_equal = std::memcmp(w1.data(), w2.data(), ne * M * sizeof(double)) == 0;
+
   double num = 0, den = 0, nodal = 0;
   for (int i = 0; i < P; ++i) {
     const double ex = std::sin(pi * xq[i]);
@@ -102,8 +117,9 @@ int main() {
   std::printf("c_abi_demo: rel-L2 vs sin(pi x) = %.4e (expect 3.255e-06), max nodal error = %.4e "
               "(expect 3.274e-06), fallback elements = %d, element of x=0: %lld (expect 11)\n",
               rel, nodal, fallback, (long long)el[100]);
+  std::printf("c_abi_demo: bound step (lssvr_step_plan_launch x 3) %s lssvr_enhance\n", plan_equal ? "bit-equal to" : "DIFFERS from");
   const bool ok = std::fabs(rel - 3.255e-6) < 5e-9 && std::fabs(nodal - 3.274e-6) < 2e-9 &&
-                  fallback == 0 && el[100] == 11 && el[0] == 0 && el[P - 1] == ne - 1;
+                  fallback == 0 && el[100] == 11 && el[0] == 0 && el[P - 1] == ne - 1 && plan_equal;
   std::printf(ok ? "OK\n" : "MISMATCH\n");
   return ok ? 0 : 5;
 }

@@ -16,7 +16,7 @@ IN_TREE_LIB = os.path.join(_HERE, "csrc", "liblssvr_hip.so")
 # test suite and the benchmark always exercise the one in-tree library.
 LIB_PATH = os.environ.get("LSSVR_HIP_LIB") or IN_TREE_LIB
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 RHS_ARRAY = 0
 RHS_SIN = 1
@@ -65,6 +65,12 @@ SIGNATURES = {
                             _c_dbl, _c_dbl, _c_dbl, _c_dbl,
                             _c_int, _c_int, _c_dbl, C.POINTER(_c_dbl), _c_int,
                             _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp]),
+    "lssvr_step_plan_create": (_c_int, [C.POINTER(C.c_void_p), _c_dp, _c_dp, _c_i64, _c_i64, _c_i64,
+                                        _c_dbl, _c_dbl, _c_dbl, _c_dbl,
+                                        _c_int, _c_int, _c_dbl, C.POINTER(_c_dbl), _c_int,
+                                        _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp]),
+    "lssvr_step_plan_launch": (_c_int, [C.c_void_p, _c_dp]),
+    "lssvr_step_plan_destroy": (_c_int, [C.c_void_p]),
     "lssvr_enhance_varcoef": (_c_int, [_c_dp, _c_dp, _c_i64, _c_i64, _c_i64,
                                        _c_dbl, _c_dbl, _c_dbl, _c_dbl,
                                        _c_int, _c_int, _c_dbl,

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 
+#include <new>
 #include "lssvr_kernels.hpp"
 
 namespace {
@@ -280,12 +281,18 @@ int lssvr_enhance_profiled(const double* x, const double* u, int64_t ne, int64_t
   return dispatch_timed(a, solver_id, reinterpret_cast<hipStream_t>(stream), nullptr, 0, kernel_ms_host);
 }
 
-int lssvr_step(const double* x, const double* u, int64_t ne, int64_t elem_offset,
-               int64_t ne_global, double gxmin, double gxmax, double bc_left, double bc_right,
-               int M, int n_colloc, double gamma, const double* rhs_params_host, int nquad,
-               double* diag, double* off, double* load, double* W, int32_t* status,
-               int32_t* fail_count, void* stream) {
+// lssvr_step's arguments, validated and turned into the kernels' argument blocks: what a plan keeps
+struct lssvr_step_plan {
   lssvr::EnhanceArgs a;
+  lssvr::P1Args p;
+};
+
+static int bind_step(lssvr_step_plan& b, const double* x, const double* u, int64_t ne, int64_t elem_offset,
+                     int64_t ne_global, double gxmin, double gxmax, double bc_left, double bc_right,
+                     int M, int n_colloc, double gamma, const double* rhs_params_host, int nquad,
+                     double* diag, double* off, double* load, double* W, int32_t* status,
+                     int32_t* fail_count) {
+  lssvr::EnhanceArgs& a = b.a;
   int rc = fill_enhance_args(a, x, u, ne, elem_offset, ne_global, gxmin, gxmax, bc_left, bc_right,
                              M, n_colloc, gamma, W);
   if (rc != LSSVR_OK) return rc;
@@ -302,7 +309,8 @@ int lssvr_step(const double* x, const double* u, int64_t ne, int64_t elem_offset
   a.rhs_omega = rhs_params_host[1];
   a.status = status;
   a.fail_count = fail_count;
-  lssvr::P1Args p{};
+  lssvr::P1Args& p = b.p;
+  p = lssvr::P1Args{};
   p.x = x;
   p.ne = ne;
   p.nquad = nquad;
@@ -312,18 +320,60 @@ int lssvr_step(const double* x, const double* u, int64_t ne, int64_t elem_offset
   p.diag = diag;
   p.off = off;
   p.load = load;
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  return LSSVR_OK;
+}
+
+static int run_step(const lssvr_step_plan& b, hipStream_t s) {
+  const lssvr::EnhanceArgs& a = b.a;
+  const lssvr::P1Args& p = b.p;
   // (near-square regime, a.refine > 0: the refinement lives in a kernel of its own -- two launches)
-  if (M <= lssvr::kSmallMaxM && a.refine == 0) return check_launch(lssvr::step_small(a, p, s), "step_small");
-  if (M <= lssvr::kSmallMaxM) {
-    rc = check_launch(lssvr::p1_assemble(p, s), "p1_assemble");
-    if (rc != LSSVR_OK) return rc;
-    return check_launch(lssvr::enhance_small(a, s), "enhance_small(refine)");
-  }
-  // large degree: the enhancement is long enough that a fused launch buys nothing
-  rc = check_launch(lssvr::p1_assemble(p, s), "p1_assemble");
+  if (a.M <= lssvr::kSmallMaxM && a.refine == 0) return check_launch(lssvr::step_small(a, p, s), "step_small");
+  int rc = check_launch(lssvr::p1_assemble(p, s), "p1_assemble");
   if (rc != LSSVR_OK) return rc;
+  if (a.M <= lssvr::kSmallMaxM) return check_launch(lssvr::enhance_small(a, s), "enhance_small(refine)");
+  // large degree: the enhancement is long enough that a fused launch buys nothing
   return check_launch(lssvr::enhance_large(a, s), "enhance_large");
+}
+
+int lssvr_step(const double* x, const double* u, int64_t ne, int64_t elem_offset,
+               int64_t ne_global, double gxmin, double gxmax, double bc_left, double bc_right,
+               int M, int n_colloc, double gamma, const double* rhs_params_host, int nquad,
+               double* diag, double* off, double* load, double* W, int32_t* status,
+               int32_t* fail_count, void* stream) {
+  lssvr_step_plan b;
+  const int rc = bind_step(b, x, u, ne, elem_offset, ne_global, gxmin, gxmax, bc_left, bc_right, M, n_colloc,
+                           gamma, rhs_params_host, nquad, diag, off, load, W, status, fail_count);
+  if (rc != LSSVR_OK) return rc;
+  return run_step(b, reinterpret_cast<hipStream_t>(stream));
+}
+
+int lssvr_step_plan_create(lssvr_step_plan** plan, const double* x, const double* u, int64_t ne,
+                           int64_t elem_offset, int64_t ne_global, double gxmin, double gxmax,
+                           double bc_left, double bc_right, int M, int n_colloc, double gamma,
+                           const double* rhs_params_host, int nquad, double* diag, double* off,
+                           double* load, double* W, int32_t* status, int32_t* fail_count) {
+  if (!plan) return fail(LSSVR_ERR_NULL, "plan must be non-NULL");
+  *plan = nullptr;
+  lssvr_step_plan* b = new (std::nothrow) lssvr_step_plan;
+  if (!b) return fail(LSSVR_ERR_LAUNCH, "out of host memory");
+  const int rc = bind_step(*b, x, u, ne, elem_offset, ne_global, gxmin, gxmax, bc_left, bc_right, M, n_colloc,
+                           gamma, rhs_params_host, nquad, diag, off, load, W, status, fail_count);
+  if (rc != LSSVR_OK) {
+    delete b;
+    return rc;
+  }
+  *plan = b;
+  return LSSVR_OK;
+}
+
+int lssvr_step_plan_launch(const lssvr_step_plan* plan, void* stream) {
+  if (!plan) return fail(LSSVR_ERR_NULL, "plan must be non-NULL");
+  return run_step(*plan, reinterpret_cast<hipStream_t>(stream));
+}
+
+int lssvr_step_plan_destroy(lssvr_step_plan* plan) {
+  delete plan;
+  return LSSVR_OK;
 }
 
 int lssvr_enhance_varcoef(const double* x, const double* u, int64_t ne, int64_t elem_offset,

@@ -377,8 +377,8 @@ def _bind(lib, name, args):
     times, and converting ~20 Python values per call is a third of the host's ~7 us per launch of an ~8 us step."""
     import ctypes
     argtypes = _capi.SIGNATURES[name][1]
-    conv = tuple(a if (a is None or isinstance(a, (ctypes.Array, ctypes._SimpleCData, ctypes._Pointer))) else tp(a)
-                 for tp, a in zip(argtypes, args))
+    ready = (ctypes.Array, ctypes._SimpleCData, ctypes._Pointer, type(ctypes.byref(ctypes.c_int())))
+    conv = tuple(a if (a is None or isinstance(a, ready)) else tp(a) for tp, a in zip(argtypes, args))
     return getattr(lib, name), conv
 
 
@@ -423,6 +423,17 @@ class StepPlan:
                       _ptr(self.bands["diag"]), _ptr(self.bands["off"]), _ptr(self.bands["load"]),
                       _ptr(self.W), _ptr(self.status), _ptr(fail_count))
         self._step, self._cargs = _bind(self.lib, "lssvr_step", self._args)
+        # the library's own plan (lssvr_step_plan_*): the 20 arguments validated and bound once on the C side, a
+        # launch is a two-argument call (host cost 4.4 -> ~2 us per launch; with the stream handle passed in, since
+        # torch.cuda.current_stream() alone costs 3 us)
+        import ctypes
+        self._handle = ctypes.c_void_p()
+        create, cargs = _bind(self.lib, "lssvr_step_plan_create", (ctypes.byref(self._handle),) + self._args)
+        rc = create(*cargs)
+        if rc < 0:
+            self._handle = None
+            _capi.check(rc, "lssvr_step_plan_create")
+        self._launch = self.lib.lssvr_step_plan_launch
 
         if self._work is not None:
             self._asm_args = (_ptr(x), ne, int(nquad), RHS_SIN, self._keep[2], None, None,
@@ -441,10 +452,19 @@ class StepPlan:
             if rc >= 0:
                 rc = self.lib.lssvr_enhance_ws(*self._enh_args, st, None)
         else:
-            rc = self._step(*self._cargs, st)
+            rc = self._launch(self._handle, st)
         if rc < 0:
             _capi.check(rc, "lssvr_step")
         return self.W, self.status
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h:
+            try:
+                self.lib.lssvr_step_plan_destroy(h)
+            except Exception:
+                pass
+            self._handle = None
 
 
 def enhance_varcoef(x, u, M, gamma, n_colloc, a_values, da_values, rhs_values, *, elem_offset=0,

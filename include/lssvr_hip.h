@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LSSVR_ABI_VERSION 4
+#define LSSVR_ABI_VERSION 5
 
 /* error codes */
 #define LSSVR_OK              0
@@ -172,6 +172,29 @@ int lssvr_step(const double* x, const double* u, int64_t ne,
                int M, int n_colloc, double gamma, const double* rhs_params_host, int nquad,
                double* diag, double* off, double* load,
                double* W, int32_t* status, int32_t* fail_count, void* stream);
+
+/*
+ * lssvr_step_plan_* -- lssvr_step bound once, launched many times.  A time-stepping caller issues the
+ * same step on the same resident buffers over and over (the reference's loop, Dual.py:139-169, re-run
+ * after every FEM solve); validating and marshalling 21 arguments per call costs a host more than the
+ * 3 us the launch itself does, and at 7-8 us per step that is what decides whether a stream stays fed.
+ *   create : the arguments of lssvr_step (without the stream), checked exactly as lssvr_step checks
+ *            them; *plan receives an opaque handle (a small HOST allocation: no device memory, no
+ *            HIP call).  The buffers are referenced, not copied: their CONTENTS may change between
+ *            launches, their addresses and sizes may not.
+ *   launch : what lssvr_step would enqueue, on `stream`; asynchronous.  A plan may be launched on any
+ *            stream, and concurrently from several threads (it is read-only after create).
+ *   destroy: frees the handle (NULL is allowed); launches already enqueued are not affected.
+ */
+typedef struct lssvr_step_plan lssvr_step_plan;
+int lssvr_step_plan_create(lssvr_step_plan** plan, const double* x, const double* u, int64_t ne,
+                           int64_t elem_offset, int64_t ne_global,
+                           double gxmin, double gxmax, double bc_left, double bc_right,
+                           int M, int n_colloc, double gamma, const double* rhs_params_host, int nquad,
+                           double* diag, double* off, double* load,
+                           double* W, int32_t* status, int32_t* fail_count);
+int lssvr_step_plan_launch(const lssvr_step_plan* plan, void* stream);
+int lssvr_step_plan_destroy(lssvr_step_plan* plan);
 
 /*
  * lssvr_enhance_varcoef -- BASELINE config 5, -(a u')' = f (no reference

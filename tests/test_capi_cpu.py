@@ -131,3 +131,28 @@ def test_enhance_work_bytes_is_host_arithmetic():
     assert wb(1000, 9, 16, _capi.SOLVER_PRIMAL_MOMENT) == 1000 * 96 * 8
     assert wb(1000, 33, 64, _capi.SOLVER_DUAL) == 0 and wb(1000, 33, 64, _capi.SOLVER_PRIMAL_WAVE) == 0
     assert wb(0, 33, 64, _capi.SOLVER_PRIMAL) == 0
+
+
+def test_step_plan_binds_and_validates_without_gpu():
+    """lssvr_step_plan_create is host arithmetic (validation + a small host allocation, no HIP call): it runs here.
+    Same checks as lssvr_step; a failed create leaves a NULL handle; destroy accepts NULL."""
+    from hybrid_fem_lssvr_amd import _capi
+    lib = _capi.load()
+    rhs = _capi.rhs_params(9.869604401089358, 3.141592653589793)
+    fake = [0x10000 * (i + 1) for i in range(8)]            # never dereferenced: the plan is not launched
+
+    def create(ne=100, M=9, n=16, nquad=2, diag=fake[2]):
+        h = ctypes.c_void_p()
+        rc = lib.lssvr_step_plan_create(ctypes.byref(h), fake[0], fake[1], ne, 0, ne, -1.0, 1.0, 0.0, 0.0, M, n, 1e4,
+                                        rhs, nquad, diag, fake[3], fake[4], fake[5], fake[6], None)
+        return rc, h
+
+    rc, h = create()
+    assert rc == 0 and h.value
+    assert lib.lssvr_step_plan_destroy(h) == 0
+    for kw in ({"nquad": 9}, {"ne": 0}, {"M": 40}, {"n": 3}, {"diag": None}):
+        rc, h = create(**kw)
+        assert rc < 0 and not h.value, kw
+        assert lib.lssvr_last_error().decode()
+    assert lib.lssvr_step_plan_destroy(None) == 0
+    assert lib.lssvr_step_plan_launch(None, None) < 0         # NULL plan: an argument error, no HIP call
