@@ -1359,7 +1359,9 @@ def measure_poisson(D, M, n, ne_glob, lo, hi, dev, steps, warmup, solver="primal
     if os.path.exists(tf) and not dual:
         try:
             tj = json.load(open(tf))
-            tr = tj.get("step_M%d_n%d_ne%d" % (M, n, ne_loc)) or tj.get("M%d_n%d_ne%d" % (M, n, ne_loc))
+            key = "step_M%d_n%d_ne%d" % (M, n, ne_loc)
+            tr = tj.get(key) or tj.get("M%d_n%d_ne%d" % (M, n, ne_loc))
+            rnd = (tj.get("_round_r04") if key in tj else None) or tj.get("_round", "committed profile")
             if tr:
                 out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
                 out["roofline_hbm"]["traffic"] = tr["hbm_bytes_per_launch"]
@@ -1367,7 +1369,7 @@ def measure_poisson(D, M, n, ne_glob, lo, hi, dev, steps, warmup, solver="primal
                     out["roofline_hbm"]["algorithmic_bytes_per_launch_with_the_p1_bands"] = \
                         tr["algorithmic_bytes_per_launch_with_the_p1_bands"]
                 out["roofline"]["traffic_source"] = ("profiles/traffic.json (%s): %s; NOT measured in this run"
-                                                     % (tj.get("_round", "committed profile"),
+                                                     % (rnd,
                                                         tr.get("what", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
                                                                        "at this size, calibrated")))
         except Exception:

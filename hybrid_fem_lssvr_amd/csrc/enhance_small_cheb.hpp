@@ -56,7 +56,7 @@ constexpr int kRefineMinM = 14; // near-square refinement of the lane kernel: in
 struct NoProbe {
   __device__ __forceinline__ void mark(int) const {}
 };
-enum LanePhase : int { kPhEntry = 0, kPhLoaded, kPhSeeded, kPhMoments, kPhSystem, kPhSolved, kPhStored, kPhCount };
+enum LanePhase : int { kPhEntry = 0, kPhArgs, kPhLoaded, kPhSeeded, kPhMoments, kPhSystem, kPhSolved, kPhStored, kPhCount };
 
 template <int M, int RHS>
 constexpr int kChebTilePerWave =
@@ -255,6 +255,7 @@ __device__ __forceinline__ void enhance_small_body_cheb(const EnhanceArgs& p, co
   [[maybe_unused]] double slowbuf[MR > 0 ? ChebSlow<M>::kSize : 1];
   [[maybe_unused]] double rflag = 0.0;
   probe.mark(kPhEntry);
+  probe.mark(kPhArgs);
   const bool scattered = p.elem_ids != nullptr || (p.ldw != 0 && p.ldw != M);
   // Every lane runs the body (lanes past the end of the last wave on a duplicate of the last
   // element, their stores masked): tabulated inputs are loaded cooperatively by the wave.

@@ -24,6 +24,7 @@ struct StampProbe {
   unsigned long long* out;      // [wave][kSlots] of this launch
   __device__ __forceinline__ void mark(int k) const {
     if (k == kPhLoaded) __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0): the element's inputs have arrived
+    if (k == kPhArgs) __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): the kernel arguments have arrived
     const unsigned long long t = __builtin_amdgcn_s_memrealtime();
     const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if ((threadIdx.x & 63) == 0) {
@@ -156,7 +157,7 @@ int main(int argc, char** argv) {
   }
   printf("launch %d of the replay, %ld waves (times in us):\n", l, waves);
   printf("  wave start after the launch's first wave : median %.2f  p90 %.2f  max %.2f\n", med(start), pct(start, 0.9), pct(start, 1.0));
-  const char* names[kPhCount] = {"", "entry -> inputs loaded (s_load + 4 global loads)", "element set-up (map, boundary data, rhs seeds)", "collocation loop (16 points: moments, rhs)",
+  const char* names[kPhCount] = {"", "entry -> kernel arguments arrived (s_load)", "-> inputs loaded (4 global loads)", "element set-up (map, boundary data, rhs seeds)", "collocation loop (16 points: moments, rhs)",
                                  "system built from the moments", "LDL^T + substitutions + v = Y z", "LDS transposition + stores issued"};
   for (int k = 1; k < kPhCount; ++k) printf("  %-52s: median %.2f  p10 %.2f  p90 %.2f\n", names[k], med(dur[k]), pct(dur[k], 0.1), pct(dur[k], 0.9));
   printf("  wave end after the launch's first wave   : median %.2f  p90 %.2f  max %.2f\n", med(endt), pct(endt, 0.9), pct(endt, 1.0));
