@@ -339,9 +339,15 @@ def test_step_refuses_rank_deficient_primal(dev):
     from hybrid_fem_lssvr_amd import ops, _capi
     nodes = np.linspace(-1, 1, 25)
     x, u = _t(nodes, dev), _t(np.sin(np.pi * nodes), dev)
-    plan = ops.StepPlan(x, u, 17, 1e4, 12, global_domain=(-1.0, 1.0))
+    # (refused when the plan is bound -- lssvr_step_plan_create validates what lssvr_step validates -- and by the
+    # unbound call as well)
     with pytest.raises(_capi.LssvrHipError, match="rank deficient"):
-        plan.launch()
+        ops.StepPlan(x, u, 17, 1e4, 12, global_domain=(-1.0, 1.0))
+    ok = ops.StepPlan(x, u, 14, 1e4, 12, global_domain=(-1.0, 1.0))
+    bad = list(ok._cargs)
+    bad[9] = type(bad[9])(17)                                  # M of the bare lssvr_step argument tuple
+    assert ok._step(*bad, torch.cuda.current_stream().cuda_stream) == -5
+    assert b"rank deficient" in ok.lib.lssvr_last_error()
     # the boundary of the regime (n == M-2) is accepted
     ops.StepPlan(x, u, 14, 1e4, 12, global_domain=(-1.0, 1.0)).launch()
     torch.cuda.synchronize()
