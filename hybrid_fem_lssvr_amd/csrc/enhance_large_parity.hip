@@ -265,23 +265,47 @@ __global__ __launch_bounds__(64 * kWaves, 2) void solve4_parity_kernel(EnhanceAr
       const double colB = inB ? 1.0 : 0.0;
       const int padrow = (nO < nE) ? nO : -1;
       asm volatile("s_nop 1" : "+v"(G1A), "+v"(G2A), "+v"(G1B), "+v"(G2B));     // DPP sources below
-      static_for<0, kPB>([&](auto tc) {
+      // LDS operands one PAIR of rows ahead of their use: the reads of rows 2g+2, 2g+3 are issued before rows 2g,
+      // 2g+1 are worked on, so their latency (two waves per SIMD, in-order issue) falls into 18 vector instructions
+      // instead of being waited for at the head of every group of four rows.  Same values, same arithmetic order.
+      struct Row { double m, pn, ne, no; };               // meM[t], meP[t + 1], NE[t][q], NO[t][q]
+      auto load_row = [&](auto tc) -> Row {
         constexpr int t = decltype(tc)::value;
-        double v = meP[t] + meM[t];
-        v = fma(eps2, NEl[t * kPB + q], v);
+        return Row{meM[t], meP[t + 1], NEl[t * kPB + q], NOl[(t < kPB - 1 ? t : 0) * kPB + q]};
+      };
+      auto build_row = [&](auto tc, const double p, const Row& r) {
+        constexpr int t = decltype(tc)::value;
+        double v = p + r.m;
+        v = fma(eps2, r.ne, v);
         fmac_rowbcast<t>(v, G1A, H1A);
         fmac_rowbcast<t>(v, G2A, H2A);
         A[t] = v;
         if constexpr (t < kPB - 1) {
-          double w = meP[t + 1] + meM[t];
-          w = fma(eps2, NOl[t * kPB + q], w);
+          double w = r.pn + r.m;
+          w = fma(eps2, r.no, w);
           fmac_rowbcast<t>(w, G1B, H1B);
           fmac_rowbcast<t>(w, G2B, H2B);
           // an odd number of bubble coefficients: the odd block is one short of the even one and
           // step nO pivots on a padding column -- that column is the unit vector, its row zero elsewhere
           B[t] = (t == padrow) ? ((q == t) ? 1.0 : 0.0) : w * colB;
         }
-        if constexpr ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      };
+      double pcur = meP[0];
+      Row r0 = load_row(std::integral_constant<int, 0>{}), r1 = load_row(std::integral_constant<int, 1>{});
+      static_for<0, kPB / 2>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        Row n0 = r0, n1 = r1;
+        if constexpr (g + 1 < kPB / 2) {
+          n0 = load_row(std::integral_constant<int, 2 * g + 2>{});
+          n1 = load_row(std::integral_constant<int, 2 * g + 3>{});
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        build_row(std::integral_constant<int, 2 * g>{}, pcur, r0);
+        build_row(std::integral_constant<int, 2 * g + 1>{}, r0.pn, r1);
+        __builtin_amdgcn_sched_barrier(0);
+        pcur = r1.pn;
+        r0 = n0;
+        r1 = n1;
       });
       B[kPB - 1] = (q == kPB - 1) ? 1.0 : 0.0;
       A[kPB] = rhsA;
@@ -310,14 +334,31 @@ __global__ __launch_bounds__(64 * kWaves, 2) void solve4_parity_kernel(EnhanceAr
       double srcA = zA, srcB = zB;
       asm volatile("s_nop 1" : "+v"(srcA), "+v"(srcB));
       double rA = 0.0, rB = 0.0;
-      static_for<0, kPB>([&](auto tc) {
-        constexpr int t = decltype(tc)::value;
-        const double m1 = moP[t];
-        if constexpr (t < kPB - 1) fmac_rowbcast<t>(rA, srcB, m1 + moM[t]);
-        fmac_rowbcast<t>(rB, srcA, m1 + (moM - 1)[t]);
-        // (four entries in flight at a time: the factor occupies the registers)
-        if constexpr ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-      });
+      {
+        // odd moments two PAIRS of rows ahead of their use (see the build above): moP[t], moM[t] of rows 2g+4, 2g+5
+        // are read while rows 2g, 2g+1 are worked on
+        struct Odd { double p0, m0, p1, m1; };            // moP[2g], moM[2g], moP[2g+1], moM[2g+1]
+        auto load_odd = [&](auto gc) -> Odd {
+          constexpr int g = decltype(gc)::value;
+          return Odd{moP[2 * g], moM[2 * g], moP[2 * g + 1], moM[2 * g + 1]};
+        };
+        double mprev = (moM - 1)[0];
+        Odd o0 = load_odd(std::integral_constant<int, 0>{}), o1 = load_odd(std::integral_constant<int, 1>{});
+        static_for<0, kPB / 2>([&](auto gc) {
+          constexpr int g = decltype(gc)::value;
+          Odd o2 = o1;
+          if constexpr (g + 2 < kPB / 2) o2 = load_odd(std::integral_constant<int, g + 2>{});
+          __builtin_amdgcn_sched_barrier(0);
+          fmac_rowbcast<2 * g>(rA, srcB, o0.p0 + o0.m0);
+          fmac_rowbcast<2 * g>(rB, srcA, o0.p0 + mprev);
+          if constexpr (2 * g + 1 < kPB - 1) fmac_rowbcast<2 * g + 1>(rA, srcB, o0.p1 + o0.m1);
+          fmac_rowbcast<2 * g + 1>(rB, srcA, o0.p1 + o0.m0);
+          __builtin_amdgcn_sched_barrier(0);
+          mprev = o0.m1;
+          o0 = o1;
+          o1 = o2;
+        });
+      }
       if (ridge_couples) {
         // first order:  ed (al_i b_c + b_i al_c);   exact:  eps2 (C0z_i C0z_c + C1z_i C1z_c)
         const double q1A = any_slow ? H1A : G2A, q2A = any_slow ? H2A : G1A;
@@ -347,11 +388,25 @@ __global__ __launch_bounds__(64 * kWaves, 2) void solve4_parity_kernel(EnhanceAr
       asm volatile("s_nop 1" : "+v"(srcA), "+v"(srcB));
       const double* const yE = YEl + q;
       const double* const yO = YOl + q;
-      static_for<0, kPB>([&](auto tc) {
-        constexpr int t = decltype(tc)::value;
-        fmac_rowbcast<t>(vA, srcA, yE[t * kPB]);
-        fmac_rowbcast<t>(vB, srcB, yO[t * kPB]);
-        if constexpr ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      // (table rows two pairs ahead of their use, as above)
+      struct Yrow { double e0, o0, e1, o1; };
+      auto load_y = [&](auto gc) -> Yrow {
+        constexpr int g = decltype(gc)::value;
+        return Yrow{yE[(2 * g) * kPB], yO[(2 * g) * kPB], yE[(2 * g + 1) * kPB], yO[(2 * g + 1) * kPB]};
+      };
+      Yrow y0 = load_y(std::integral_constant<int, 0>{}), y1 = load_y(std::integral_constant<int, 1>{});
+      static_for<0, kPB / 2>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        Yrow y2 = y1;
+        if constexpr (g + 2 < kPB / 2) y2 = load_y(std::integral_constant<int, g + 2>{});
+        __builtin_amdgcn_sched_barrier(0);
+        fmac_rowbcast<2 * g>(vA, srcA, y0.e0);
+        fmac_rowbcast<2 * g>(vB, srcB, y0.o0);
+        fmac_rowbcast<2 * g + 1>(vA, srcA, y0.e1);
+        fmac_rowbcast<2 * g + 1>(vB, srcB, y0.o1);
+        __builtin_amdgcn_sched_barrier(0);
+        y0 = y1;
+        y1 = y2;
       });
       if (!inA) vA = 0.0;
       if (!inB) vB = 0.0;
