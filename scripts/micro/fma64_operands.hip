@@ -67,6 +67,11 @@ __global__ __launch_bounds__(64) void k(double* out, long long* cyc, int iters, 
         asm volatile("v_fmac_f64_e32 %0, %1, %2" : "+v"(a) : "v"(x), "v"(y));
         if ((q & 7) == 7) asm volatile("s_add_i32 %0, %0, 1" : "+s"(it2));
       }
+      if constexpr (KIND == 16) asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "+v"(a) : "v"(x), "v"(y));   // DPP broadcast operand
+      if constexpr (KIND == 17) {                                                                                      // the parity factorisation's mix: 3 DPP : 1 plain
+        if ((q & 3) == 3) asm volatile("v_fmac_f64_e32 %0, %1, %2" : "+v"(a) : "v"(x), "v"(y));
+        else asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:5 row_mask:0xf bank_mask:0xf" : "+v"(a) : "v"(x), "v"(y));
+      }
       if constexpr (KIND == 10) {                                                                                      // 32-bit FMA for scale
         float& f = reinterpret_cast<float*>(&a)[0];
         asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(f) : "v"(reinterpret_cast<float*>(&x)[0]), "v"(reinterpret_cast<float*>(&y)[0]));
@@ -146,6 +151,7 @@ int main() {
   sweep<12>("alternating v_fma_f64 / v_mul_f64", cus, iters);
   sweep<13>("lane-loop mix: 4 v_fmac : 2 v_add : 1 v_mul", cus, iters);
   sweep<14>("the same mix, add and mul written as v_fma_f64", cus, iters);
-  sweep<15>("v_fmac_f64 with an s_add_i32 after every 8th", cus, iters);
+  sweep<16>("v_fmac_f64_dpp row_newbcast (DPP operand)", cus, iters);
+  sweep<17>("3 v_fmac_f64_dpp : 1 v_fmac_f64", cus, iters);
   return 0;
 }
