@@ -40,12 +40,27 @@ struct StampProbe {
   }
 };
 
-__global__ __launch_bounds__(kBlock) void probed_kernel(EnhanceArgs p, unsigned long long* stamps) {
+// LSSVR_PRELOAD (build with -mllvm -amdgpu-kernarg-preload-count=16): the pointers and counts the first loads need as
+// LEADING SCALAR parameters (64 bytes = 16 SGPRs), which the command processor can place in SGPRs before the wave
+// starts -- does the "kernel arguments arrived" phase go away?
+#ifdef LSSVR_PRELOAD
+#define LEAD const double* x_, const double* u_, long long ne_, const long long* ids_, const double* gam_, double* W_, int* st_, long long nem_,
+#define FIX(p) p.x = x_; p.u = u_; p.ne = ne_; p.elem_ids = (const int64_t*)ids_; p.gamma_values = gam_; p.W = W_; p.status = st_; p.ne_mesh = nem_;
+#define LEADARGS(a) a.x, a.u, (long long)a.ne, (const long long*)a.elem_ids, a.gamma_values, a.W, a.status, (long long)a.ne_mesh,
+#else
+#define LEAD
+#define FIX(p)
+#define LEADARGS(a)
+#endif
+
+__global__ __launch_bounds__(kBlock) void probed_kernel(LEAD EnhanceArgs p, unsigned long long* stamps) {
+  FIX(p)
   __shared__ double tile[(kBlock / 64) * kChebTilePerWave<9, LSSVR_RHS_SIN>];
   enhance_small_body_cheb<9, LSSVR_RHS_SIN, false, StampProbe>(p, blockIdx.x, tile, StampProbe{stamps});
 }
 
-__global__ __launch_bounds__(kBlock) void plain_kernel(EnhanceArgs p) {
+__global__ __launch_bounds__(kBlock) void plain_kernel(LEAD EnhanceArgs p) {
+  FIX(p)
   __shared__ double tile[(kBlock / 64) * kChebTilePerWave<9, LSSVR_RHS_SIN>];
   enhance_small_body_cheb<9, LSSVR_RHS_SIN>(p, blockIdx.x, tile);
 }
@@ -90,8 +105,8 @@ int main(int argc, char** argv) {
     hipGraph_t g; hipGraphExec_t ge;
     hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
     for (int i = 0; i < K; ++i) {
-      if (probed) hipLaunchKernelGGL(probed_kernel, dim3(blocks), dim3(kBlock), 0, s, a, dstamp + (size_t)i * waves * kSlots);
-      else hipLaunchKernelGGL(plain_kernel, dim3(blocks), dim3(kBlock), 0, s, a);
+      if (probed) hipLaunchKernelGGL(probed_kernel, dim3(blocks), dim3(kBlock), 0, s, LEADARGS(a) a, dstamp + (size_t)i * waves * kSlots);
+      else hipLaunchKernelGGL(plain_kernel, dim3(blocks), dim3(kBlock), 0, s, LEADARGS(a) a);
     }
     hipStreamEndCapture(s, &g);
     hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
