@@ -380,36 +380,11 @@ __device__ __forceinline__ void enhance_small_body(const EnhanceArgs& p, const u
   }
 }
 
-// KERNEL-ARGUMENT PRELOAD (Makefile: -mllvm -amdgpu-kernarg-preload-count=16).  A wave's first instructions need eight
-// numbers out of ~430 bytes of arguments: passed as LEADING SCALAR parameters (64 bytes = 16 SGPRs) the command
-// processor places them in registers before the wave starts, so the loads of x[e], x[e+1], u[e], u[e+1] are issued at
-// once instead of after the round trip of the argument fetch (0.45 us) -- the two latencies overlap instead of adding
-// up: launch period 7.75 -> 7.57-7.62 us at 100 008 elements (scripts/micro/lane_phases.hip, -DLSSVR_PRELOAD).  The
-// structs still carry the same fields (hosts fill both); where the firmware does not preload, the kernel's
-// backward-compatible prologue loads them.
-#define LSSVR_LEAD_PARAMS                                                                                       \
-  unsigned lead_eblocks, unsigned lead_pad, long long lead_ne, const long long* lead_ids, const double* lead_x, \
-      const double* lead_u, const double* lead_gam, long long lead_eoff, long long lead_neg
-#define LSSVR_LEAD_APPLY(p)                          \
-  (p).ne = lead_ne;                                  \
-  (p).elem_ids = (const int64_t*)lead_ids;           \
-  (p).x = lead_x;                                    \
-  (p).u = lead_u;                                    \
-  (p).gamma_values = lead_gam;                       \
-  (p).elem_offset = lead_eoff;                       \
-  (p).ne_global = lead_neg;                          \
-  (void)lead_pad;
-#define LSSVR_LEAD_ARGS(eb, e)                                                                             \
-  (unsigned)(eb), 0u, (long long)(e).ne, (const long long*)(e).elem_ids, (e).x, (e).u, (e).gamma_values,  \
-      (long long)(e).elem_offset, (long long)(e).ne_global
-
 // MINW = minimum waves per SIMD the register allocator must leave room for.  1 (the only value
 // dispatched): no constraint -- 136 VGPRs at M = 9 with the trigonometric coefficients in SGPRs,
 // three resident waves.
 template <int M, int RHS, bool VC, int MINW>
-__global__ __launch_bounds__(kBlock, MINW) void enhance_small_kernel(LSSVR_LEAD_PARAMS, EnhanceArgs p) {
-  LSSVR_LEAD_APPLY(p)
-  (void)lead_eblocks;
+__global__ __launch_bounds__(kBlock, MINW) void enhance_small_kernel(EnhanceArgs p) {
   if constexpr (VC) {
     __shared__ double tile[(kBlock / 64) * kSmallTilePerWave<M, RHS, VC>];
     enhance_small_body<M, RHS, VC>(p, blockIdx.x, tile);
@@ -422,9 +397,7 @@ __global__ __launch_bounds__(kBlock, MINW) void enhance_small_kernel(LSSVR_LEAD_
 
 // The Poisson lane kernel with the near-square refinement loop (launches with p.refine > 0 only)
 template <int M, int RHS>
-__global__ __launch_bounds__(kBlock) void enhance_small_refine_kernel(LSSVR_LEAD_PARAMS, EnhanceArgs p) {
-  LSSVR_LEAD_APPLY(p)
-  (void)lead_eblocks;
+__global__ __launch_bounds__(kBlock) void enhance_small_refine_kernel(EnhanceArgs p) {
   __shared__ double tile[(kBlock / 64) * kChebTilePerWave<M, RHS>];
   enhance_small_body_cheb<M, RHS, true>(p, blockIdx.x, tile);
 }
@@ -434,11 +407,8 @@ __global__ __launch_bounds__(kBlock) void enhance_small_refine_kernel(LSSVR_LEAD
 // per node).  The two halves share nothing but the node array, so fusing them only removes
 // a launch boundary and lets the short assembly run in the shadow of the enhancement.
 template <int M>
-__global__ __launch_bounds__(kBlock) void step_small_kernel(LSSVR_LEAD_PARAMS, EnhanceArgs p, P1Args a, QuadRule q) {
-  LSSVR_LEAD_APPLY(p)
-  const unsigned eblocks = lead_eblocks;
-  a.x = lead_x;
-  a.ne = lead_ne;
+__global__ __launch_bounds__(kBlock) void step_small_kernel(EnhanceArgs p, P1Args a, QuadRule q,
+                                                             unsigned eblocks) {
   __shared__ double tile[kBlock * M];
   if (blockIdx.x < eblocks) {
     enhance_small_body_cheb<M, LSSVR_RHS_SIN>(p, blockIdx.x, tile);
@@ -453,11 +423,8 @@ __global__ __launch_bounds__(kBlock) void step_small_kernel(LSSVR_LEAD_PARAMS, E
 // kStepVcMaxM (the direct-Gram bodies grow as M^2: above, lssvr_step_varcoef issues two launches).
 constexpr int kStepVcMaxM = 12;
 template <int M, int RHS>
-__global__ __launch_bounds__(kBlock) void step_small_vc_kernel(LSSVR_LEAD_PARAMS, EnhanceArgs p, P1Args a, QuadRule q) {
-  LSSVR_LEAD_APPLY(p)
-  const unsigned eblocks = lead_eblocks;
-  a.x = lead_x;
-  a.ne = lead_ne;
+__global__ __launch_bounds__(kBlock) void step_small_vc_kernel(EnhanceArgs p, P1Args a, QuadRule q,
+                                                                unsigned eblocks) {
   __shared__ double tile[(kBlock / 64) * kSmallTilePerWave<M, RHS, true>];
   if (blockIdx.x < eblocks) {
     enhance_small_body<M, RHS, true>(p, blockIdx.x, tile);
@@ -477,9 +444,9 @@ static hipError_t launch_small(const EnhanceArgs& a, hipStream_t s, const Launch
   // over above 2e5 elements; since the Chebyshev-moment body needs 136 VGPRs it loses: 406 against
   // 388 us at 1e7 elements, 41.9 against 41.3 at 1e6, same run.)
   if constexpr (!VC && M >= kRefineMinM) {
-    if (a.refine > 0) return launch(enhance_small_refine_kernel<M, RHS>, dim3(blocks), dim3(kBlock), s, o, LSSVR_LEAD_ARGS(0, a), a);
+    if (a.refine > 0) return launch(enhance_small_refine_kernel<M, RHS>, dim3(blocks), dim3(kBlock), s, o, a);
   }
-  return launch(enhance_small_kernel<M, RHS, VC, 1>, dim3(blocks), dim3(kBlock), s, o, LSSVR_LEAD_ARGS(0, a), a);
+  return launch(enhance_small_kernel<M, RHS, VC, 1>, dim3(blocks), dim3(kBlock), s, o, a);
 }
 
 template <int M>
@@ -487,7 +454,7 @@ static hipError_t launch_step(const EnhanceArgs& e, const P1Args& a, const QuadR
                               hipStream_t s, const LaunchOpts* o) {
   const unsigned eb = (unsigned)((e.ne + kBlock - 1) / kBlock);
   const unsigned ab = (unsigned)((a.ne + 1 + kBlock - 1) / kBlock);
-  return launch(step_small_kernel<M>, dim3(eb + ab), dim3(kBlock), s, o, LSSVR_LEAD_ARGS(eb, e), e, a, q);
+  return launch(step_small_kernel<M>, dim3(eb + ab), dim3(kBlock), s, o, e, a, q, eb);
 }
 
 template <int M>
@@ -497,8 +464,8 @@ static hipError_t launch_step_vc(const EnhanceArgs& e, const P1Args& a, const Qu
     const unsigned eb = (unsigned)((e.ne + kBlock - 1) / kBlock);
     const unsigned ab = (unsigned)((a.ne + 1 + kBlock - 1) / kBlock);
     if (e.tab_ps != 1)
-      return launch(step_small_vc_kernel<M, LSSVR_RHS_ARRAY_PM>, dim3(eb + ab), dim3(kBlock), s, o, LSSVR_LEAD_ARGS(eb, e), e, a, q);
-    return launch(step_small_vc_kernel<M, LSSVR_RHS_ARRAY>, dim3(eb + ab), dim3(kBlock), s, o, LSSVR_LEAD_ARGS(eb, e), e, a, q);
+      return launch(step_small_vc_kernel<M, LSSVR_RHS_ARRAY_PM>, dim3(eb + ab), dim3(kBlock), s, o, e, a, q, eb);
+    return launch(step_small_vc_kernel<M, LSSVR_RHS_ARRAY>, dim3(eb + ab), dim3(kBlock), s, o, e, a, q, eb);
   } else {
     return hipErrorInvalidValue;
   }
